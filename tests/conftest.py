@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this process")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name: str) -> dict:
+    return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=True)
+
+
+def golden_names() -> list[str]:
+    return sorted(f[:-3] for f in os.listdir(GOLDEN) if f.endswith(".pt") and f != "g07_ops.pt")

@@ -1,0 +1,70 @@
+"""The CPU oracle reproduces the live reference's outputs stored in tests/golden/ (CPU, no GPU)."""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import vit_oracle as O
+
+DT = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+
+
+def cfg_from(fix) -> O.OracleConfig:
+    kw = dict(fix["cfg"])
+    kw["dtype"] = DT[kw["dtype"]]
+    return O.OracleConfig(**kw)
+
+
+def tol(mode):
+    # fp32: same ATen kernels, same order -> equal up to threading; bf16: identical ops, allow 1 ulp-ish
+    return dict(rtol=1e-5, atol=1e-6) if mode == "fp32" else dict(rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_fixture(name):
+    fix = load_golden(name)
+    cfg = cfg_from(fix)
+    ac = torch.bfloat16 if fix["mode"] == "autocast_bf16" else None
+    sd, x = fix["state"], fix["x"]
+    torch.set_num_threads(1)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=ac is not None):
+        ev = O.vit_forward(cfg, sd, x, training=False)
+        ev2 = O.vit_forward(cfg, sd, x, training=False, output_norm=False)
+    torch.testing.assert_close(ev, fix["eval_out"], **tol(fix["mode"]))
+    torch.testing.assert_close(ev2, fix["eval_out_nonorm"], **tol(fix["mode"]))
+    assert ev.dtype == fix["eval_out"].dtype
+
+    r = O.run_fwd_bwd(cfg, sd, x, training=True, autocast=ac, seed=fix["train_seed"])
+    torch.testing.assert_close(r["out"], fix["train_out"], **tol(fix["mode"]))
+    torch.testing.assert_close(r["x_grad"], fix["x_grad"], **tol(fix["mode"]))
+    assert set(r["grads"]) == set(fix["grads"])
+    for k, g in fix["grads"].items():
+        torch.testing.assert_close(r["grads"][k], g, **tol(fix["mode"]), msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_op_level_vectors():
+    fix = load_golden("g07_ops")
+    for tag in ("fp32", "bf16"):
+        x, w, b = fix[f"norm_x_{tag}"], fix[f"norm_w_{tag}"], fix[f"norm_b_{tag}"]
+        assert torch.equal(O.apply_norm(x, w, None, 1e-5, False), fix[f"rms_eps1e-5_{tag}"])
+        assert torch.equal(O.apply_norm(x, w, None, None, False), fix[f"rms_epsNone_{tag}"])
+        assert torch.equal(O.apply_norm(x, w, b, 1e-5, True), fix[f"ln_eps1e-5_{tag}"])
+        dt = x.dtype
+        periods = O.rope_periods(64, 100.0, dt)
+        assert torch.equal(periods, fix[f"rope_periods_{tag}"])
+        table = O.rope_table(3, 5, periods, dt)
+        assert torch.equal(table, fix[f"rope_table_{tag}"])
+        assert torch.equal(O.apply_rope(fix[f"rope_q_{tag}"], table), fix[f"rope_out_{tag}"])
+    assert torch.equal(O.apply_rope(fix["rope_q_bf16"], fix["rope_table_fp32"]), fix["rope_out_bf16_x_fp32_table"])
+
+
+def test_rmsnorm_default_eps_is_opmath_epsilon():
+    # nn.RMSNorm(eps=None) (vit/vit.py:316): with torch 2.10 the default resolves to finfo(float32).eps
+    # for fp32 AND bf16 inputs (the statistic is computed in the fp32 op-math type), measured here:
+    x = torch.full((1, 8), 1e-3)
+    w = torch.ones(8)
+    for dt in (torch.float32, torch.bfloat16):
+        xd = x.to(dt)
+        y = O.apply_norm(xd, w.to(dt), None, None, False).float()[0, 0].item()
+        ms = xd.float().square().mean().item()
+        eps = (xd[0, 0].float().item() / y) ** 2 - ms
+        assert abs(eps - torch.finfo(torch.float32).eps) < 3e-8 if dt == torch.float32 else abs(eps) < 5e-7

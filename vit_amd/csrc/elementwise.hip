@@ -1,0 +1,680 @@
+// Bandwidth-bound kernels of the ViT encoder path: RMSNorm/LayerNorm fwd/bwd, row reductions,
+// MLP activations (plain and GLU), RoPE on the packed projection, patch unfolding, gradient preparation.
+// All of them stream rows with 4-wide vector accesses (16 B fp32 / 8 B bf16 per lane), fp32 math.
+#include "common.h"
+#include <string>
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+int vitk_set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+extern "C" const char* vitk_last_error(void) { return g_err.c_str(); }
+extern "C" int vitk_version(void) { return 100; }
+
+#define DISPATCH_DTYPE(code, T, ...)                \
+  if ((code) == VITK_F32) { using T = float; __VA_ARGS__; } \
+  else { using T = bf16; __VA_ARGS__; }
+
+// ------------------------------------------------------------------------------------------------
+// normalisation forward: one wave per row, rows grid-strided
+// ------------------------------------------------------------------------------------------------
+template <class TX, class TY, class TW, bool LN>
+__global__ __launch_bounds__(256) void norm_fwd_k(const TX* __restrict__ x, const TW* __restrict__ w,
+                                                  const TW* __restrict__ b, TY* __restrict__ y,
+                                                  float* __restrict__ rstd_out, float* __restrict__ mean_out,
+                                                  const int64_t* __restrict__ row_idx, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float invD = 1.f / (float)D;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t src = row_idx ? row_idx[r] : r;
+    const TX* xr = x + src * D;
+    float mean = 0.f;
+    if (LN) {
+      float s = 0.f;
+      for (int d = lane * 4; d < D; d += 256) {
+        Vec4<TX> v; v.load(xr + d);
+        s += (v.v[0] + v.v[1]) + (v.v[2] + v.v[3]);
+      }
+      mean = wave_sum(s) * invD;
+    }
+    float s2 = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      Vec4<TX> v; v.load(xr + d);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { float c = v.v[i] - mean; s2 += c * c; }
+    }
+    const float var = wave_sum(s2) * invD;
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) {
+      rstd_out[r] = rstd;
+      if (LN) mean_out[r] = mean;
+    }
+    TY* yr = y + r * D;
+    for (int d = lane * 4; d < D; d += 256) {
+      Vec4<TX> v; v.load(xr + d);
+      Vec4<TW> wv; wv.load(w + d);
+      Vec4<TY> o;
+      if (LN && b) {
+        Vec4<TW> bv; bv.load(b + d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) o.v[i] = (v.v[i] - mean) * rstd * wv.v[i] + bv.v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o.v[i] = (v.v[i] - mean) * rstd * wv.v[i];
+      }
+      o.store(yr + d);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalisation backward.  Per row, with g = dy*w, xh = (x-mean)*rstd:
+//   RMS: dx = rstd*(g - xh*mean(g*xh))        LN: dx = rstd*(g - mean(g) - xh*mean(g*xh))
+// dw = sum_r dy*xh, db = sum_r dy: each wave keeps its share in registers (MAXIT*4 floats),
+// the 4 waves of a block combine through LDS, one partial row per block goes to the workspace.
+// ------------------------------------------------------------------------------------------------
+template <class TG, class TX, class TW, class TO, bool LN, int MAXIT>
+__global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, const TX* __restrict__ x,
+                                                  const TW* __restrict__ w, const float* __restrict__ rstd_in,
+                                                  const float* __restrict__ mean_in, const TO* add, TO* dx,
+                                                  const int64_t* __restrict__ row_idx, int64_t rows, int D,
+                                                  float* __restrict__ partial /* [grid][2][D] */, int want_dw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][2][D]
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float invD = 1.f / (float)D;
+  float aw[MAXIT][4], ab[MAXIT][4];
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) { aw[it][i] = 0.f; ab[it][i] = 0.f; }
+
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t src = row_idx ? row_idx[r] : r;
+    const TX* xr = x + src * D;
+    const TG* gr = dy + r * D;
+    const float rstd = rstd_in[r];
+    const float mean = LN ? mean_in[r] : 0.f;
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int d = it * 256 + lane * 4;
+      if (d < D) {
+        Vec4<TX> xv; xv.load(xr + d);
+        Vec4<TG> gv; gv.load(gr + d);
+        Vec4<TW> wv; wv.load(w + d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float xh = (xv.v[i] - mean) * rstd;
+          const float g = gv.v[i] * wv.v[i];
+          c1 += g;
+          c2 += g * xh;
+          aw[it][i] += gv.v[i] * xh;
+          ab[it][i] += gv.v[i];
+        }
+      }
+    }
+    c2 = wave_sum(c2) * invD;
+    c1 = LN ? wave_sum(c1) * invD : 0.f;
+    TO* outr = dx + src * D;
+    const TO* addr = add ? add + src * D : nullptr;
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int d = it * 256 + lane * 4;
+      if (d < D) {
+        Vec4<TX> xv; xv.load(xr + d);
+        Vec4<TG> gv; gv.load(gr + d);
+        Vec4<TW> wv; wv.load(w + d);
+        Vec4<TO> o;
+        if (addr) o.load(addr + d);
+        else { o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float xh = (xv.v[i] - mean) * rstd;
+          const float g = gv.v[i] * wv.v[i];
+          o.v[i] += rstd * (g - c1 - xh * c2);
+        }
+        o.store(outr + d);
+      }
+    }
+  }
+  if (!want_dw) return;
+  float* mine = lds + (size_t)wid * 2 * D;
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++) {
+    const int d = it * 256 + lane * 4;
+    if (d < D) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { mine[d + i] = aw[it][i]; mine[D + d + i] = ab[it][i]; }
+    }
+  }
+  __syncthreads();
+  float* prow = partial + (size_t)blockIdx.x * 2 * D;
+  for (int i = threadIdx.x; i < 2 * D; i += 256)
+    prow[i] = (lds[i] + lds[2 * D + i]) + (lds[4 * D + i] + lds[6 * D + i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: out[n] = scale * sum_r a[ra(r), n] * (b ? b[r, n] : 1).  Stage 1 gives one partial row
+// per block row-chunk; stage 2 (same kernel, fp32 input) folds the partials.
+// ------------------------------------------------------------------------------------------------
+template <class TA, class TB, class TO>
+__global__ __launch_bounds__(256) void colsum_k(const TA* __restrict__ a, int64_t lda, const int64_t* __restrict__ a_idx,
+                                                const TB* __restrict__ b, int64_t ldb, TO* __restrict__ out,
+                                                int64_t out_ld, int64_t rows, int64_t N, float scale) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int64_t chunk = ceil_div(rows, (int64_t)gridDim.y);
+  const int64_t r0 = (int64_t)blockIdx.y * chunk;
+  const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  float s0 = 0.f, s1 = 0.f;
+  int64_t r = r0;
+  for (; r + 1 < r1; r += 2) {
+    const int64_t ra0 = a_idx ? a_idx[r] : r, ra1 = a_idx ? a_idx[r + 1] : r + 1;
+    float v0 = to_f<TA>(a[ra0 * lda + n]), v1 = to_f<TA>(a[ra1 * lda + n]);
+    if (b) { v0 *= to_f<TB>(b[r * ldb + n]); v1 *= to_f<TB>(b[(r + 1) * ldb + n]); }
+    s0 += v0; s1 += v1;
+  }
+  if (r < r1) {
+    const int64_t ra0 = a_idx ? a_idx[r] : r;
+    float v0 = to_f<TA>(a[ra0 * lda + n]);
+    if (b) v0 *= to_f<TB>(b[r * ldb + n]);
+    s0 += v0;
+  }
+  out[(int64_t)blockIdx.y * out_ld + n] = from_f<TO>((s0 + s1) * scale);
+}
+
+static const int COLSUM_CHUNKS = 256;
+extern "C" size_t vitk_colsum_workspace_bytes(int64_t N) { return (size_t)COLSUM_CHUNKS * (size_t)N * sizeof(float); }
+
+template <class TA, class TB>
+static int colsum_launch(const void* a, int64_t lda, const int64_t* a_idx, const void* b, int64_t ldb, void* out,
+                         int out_dtype, int64_t rows, int64_t N, float scale, void* ws, hipStream_t st) {
+  int chunks = (int)(rows < COLSUM_CHUNKS * 4 ? ceil_div(rows, 4) : COLSUM_CHUNKS);
+  if (chunks < 1) chunks = 1;
+  dim3 grid((unsigned)ceil_div(N, 256), (unsigned)chunks);
+  if (chunks == 1) {
+    if (out_dtype == VITK_F32)
+      hipLaunchKernelGGL((colsum_k<TA, TB, float>), grid, dim3(256), 0, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb,
+                         (float*)out, N, rows, N, scale);
+    else
+      hipLaunchKernelGGL((colsum_k<TA, TB, bf16>), grid, dim3(256), 0, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb,
+                         (bf16*)out, N, rows, N, scale);
+    VITK_LAUNCH_CHECK("colsum");
+    return 0;
+  }
+  VITK_REQUIRE(ws != nullptr, "colsum: workspace required");
+  hipLaunchKernelGGL((colsum_k<TA, TB, float>), grid, dim3(256), 0, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb,
+                     (float*)ws, N, rows, N, scale);
+  dim3 grid2((unsigned)ceil_div(N, 256), 1);
+  if (out_dtype == VITK_F32)
+    hipLaunchKernelGGL((colsum_k<float, float, float>), grid2, dim3(256), 0, st, (const float*)ws, N, nullptr,
+                       (const float*)nullptr, 0, (float*)out, N, (int64_t)chunks, N, 1.f);
+  else
+    hipLaunchKernelGGL((colsum_k<float, float, bf16>), grid2, dim3(256), 0, st, (const float*)ws, N, nullptr,
+                       (const float*)nullptr, 0, (bf16*)out, N, (int64_t)chunks, N, 1.f);
+  VITK_LAUNCH_CHECK("colsum");
+  return 0;
+}
+
+extern "C" int vitk_colsum(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, const void* b, int b_dtype,
+                           int64_t ldb, void* out, int out_dtype, int64_t rows, int64_t N, float scale, void* workspace,
+                           void* stream) {
+  VITK_REQUIRE(a && out && rows >= 0 && N > 0, "colsum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) {
+    (void)hipMemsetAsync(out, 0, (size_t)N * (out_dtype == VITK_F32 ? 4 : 2), st);
+    return 0;
+  }
+  DISPATCH_DTYPE(a_dtype, TA, {
+    DISPATCH_DTYPE(b ? b_dtype : VITK_F32, TB,
+                   { return colsum_launch<TA, TB>(a, lda, a_idx, b, ldb, out, out_dtype, rows, N, scale, workspace, st); });
+  });
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// norm entry points
+// ------------------------------------------------------------------------------------------------
+static int norm_grid(int64_t rows) {
+  int64_t g = ceil_div(rows, 4);
+  return (int)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
+}
+
+template <class TX, class TY, class TW>
+static void norm_fwd_launch(const void* x, const void* w, const void* b, void* y, float* rstd, float* mean,
+                            const int64_t* idx, int64_t rows, int D, float eps, int ln, hipStream_t st) {
+  dim3 grid(norm_grid(rows)), block(256);
+  if (ln)
+    hipLaunchKernelGGL((norm_fwd_k<TX, TY, TW, true>), grid, block, 0, st, (const TX*)x, (const TW*)w, (const TW*)b,
+                       (TY*)y, rstd, mean, idx, rows, D, eps);
+  else
+    hipLaunchKernelGGL((norm_fwd_k<TX, TY, TW, false>), grid, block, 0, st, (const TX*)x, (const TW*)w, (const TW*)b,
+                       (TY*)y, rstd, mean, idx, rows, D, eps);
+}
+
+extern "C" int vitk_norm_fwd(const void* x, int x_dtype, const void* w, const void* b, int w_dtype, void* y, int y_dtype,
+                             float* rstd, float* mean, const int64_t* row_idx, int64_t rows, int64_t D, float eps,
+                             int is_layernorm, void* stream) {
+  VITK_REQUIRE(x && w && y && rstd, "norm_fwd: null pointer");
+  VITK_REQUIRE(!is_layernorm || mean, "norm_fwd: LayerNorm needs a mean buffer");
+  VITK_REQUIRE(D > 0 && D % 4 == 0 && D <= (1 << 20), "norm_fwd: D=%lld must be a positive multiple of 4", (long long)D);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DTYPE(x_dtype, TX, {
+    DISPATCH_DTYPE(y_dtype, TY, {
+      DISPATCH_DTYPE(w_dtype, TW,
+                     { norm_fwd_launch<TX, TY, TW>(x, w, b, y, rstd, mean, row_idx, rows, (int)D, eps, is_layernorm, st); });
+    });
+  });
+  VITK_LAUNCH_CHECK("norm_fwd");
+  return 0;
+}
+
+static const int NORM_BWD_BLOCKS = 512;
+extern "C" size_t vitk_norm_bwd_workspace_bytes(int64_t D) { return (size_t)NORM_BWD_BLOCKS * 2 * (size_t)D * sizeof(float); }
+
+template <class TG, class TX, class TW, class TO, bool LN>
+static int norm_bwd_launch(const void* dy, const void* x, const void* w, const float* rstd, const float* mean,
+                           const void* add, void* dx, const int64_t* idx, int64_t rows, int D, float* ws, int want_dw,
+                           int grid, hipStream_t st) {
+  const size_t lds = want_dw ? (size_t)8 * D * sizeof(float) : 0;
+#define NB_LAUNCH(MAXIT)                                                                                            \
+  hipLaunchKernelGGL((norm_bwd_k<TG, TX, TW, TO, LN, MAXIT>), dim3(grid), dim3(256), lds, st, (const TG*)dy,        \
+                     (const TX*)x, (const TW*)w, rstd, mean, (const TO*)add, (TO*)dx, idx, rows, D, ws, want_dw)
+  if (D <= 512) NB_LAUNCH(2);
+  else if (D <= 1024) NB_LAUNCH(4);
+  else if (D <= 2048) NB_LAUNCH(8);
+  else return vitk_set_error("norm_bwd: D=%d > 2048 not supported", D);
+#undef NB_LAUNCH
+  return 0;
+}
+
+extern "C" int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* w, int w_dtype,
+                             const float* rstd, const float* mean, const void* add, void* dx, int dx_dtype, void* dw,
+                             void* db, const int64_t* row_idx, int64_t rows, int64_t D, int is_layernorm, void* workspace,
+                             void* stream) {
+  VITK_REQUIRE(dy && x && w && rstd && dx, "norm_bwd: null pointer");
+  VITK_REQUIRE(!is_layernorm || mean, "norm_bwd: LayerNorm needs the saved mean");
+  VITK_REQUIRE(D > 0 && D % 4 == 0, "norm_bwd: D=%lld must be a positive multiple of 4", (long long)D);
+  hipStream_t st = (hipStream_t)stream;
+  const int want_dw = dw != nullptr;
+  VITK_REQUIRE(!want_dw || workspace, "norm_bwd: workspace required for dw");
+  const size_t wbytes = (size_t)D * (w_dtype == VITK_F32 ? 4 : 2);
+  if (rows == 0) {
+    if (dw) (void)hipMemsetAsync(dw, 0, wbytes, st);
+    if (db) (void)hipMemsetAsync(db, 0, wbytes, st);
+    return 0;
+  }
+  int grid = norm_grid(rows);
+  if (grid > NORM_BWD_BLOCKS) grid = NORM_BWD_BLOCKS;
+  int rc = 0;
+  DISPATCH_DTYPE(dy_dtype, TG, {
+    DISPATCH_DTYPE(x_dtype, TX, {
+      DISPATCH_DTYPE(w_dtype, TW, {
+        DISPATCH_DTYPE(dx_dtype, TO, {
+          if (is_layernorm)
+            rc = norm_bwd_launch<TG, TX, TW, TO, true>(dy, x, w, rstd, mean, add, dx, row_idx, rows, (int)D,
+                                                       (float*)workspace, want_dw, grid, st);
+          else
+            rc = norm_bwd_launch<TG, TX, TW, TO, false>(dy, x, w, rstd, mean, add, dx, row_idx, rows, (int)D,
+                                                        (float*)workspace, want_dw, grid, st);
+        });
+      });
+    });
+  });
+  if (rc) return rc;
+  VITK_LAUNCH_CHECK("norm_bwd");
+  if (want_dw) {
+    // fold the per-block partials [grid][2][D]: dw = first half, db = second half
+    dim3 g2((unsigned)ceil_div(D, 256), 1);
+    const float* ws = (const float*)workspace;
+    for (int which = 0; which < 2; which++) {
+      void* dst = which == 0 ? dw : db;
+      if (!dst) continue;
+      if (w_dtype == VITK_F32)
+        hipLaunchKernelGGL((colsum_k<float, float, float>), g2, dim3(256), 0, st, ws + (size_t)which * D, 2 * D, nullptr,
+                           (const float*)nullptr, 0, (float*)dst, D, (int64_t)grid, D, 1.f);
+      else
+        hipLaunchKernelGGL((colsum_k<float, float, bf16>), g2, dim3(256), 0, st, ws + (size_t)which * D, 2 * D, nullptr,
+                           (const float*)nullptr, 0, (bf16*)dst, D, (int64_t)grid, D, 1.f);
+    }
+    VITK_LAUNCH_CHECK("norm_bwd reduce");
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP activation forward/backward (plain and GLU).  In bf16 every eager op rounds its result, so
+// act(glu) and the product are rounded separately to stay close to the eager arithmetic.
+// ------------------------------------------------------------------------------------------------
+template <class T, bool GLU>
+__global__ __launch_bounds__(256) void act_fwd_k(const T* __restrict__ p, T* __restrict__ h, int64_t rows, int64_t F,
+                                                 int act, int use_limit, float limit, int use_extra, float extra,
+                                                 uint32_t thr, float keep_scale, uint64_t seed) {
+  const int64_t nvec = rows * (F / 4);
+  const int64_t ldp = GLU ? 2 * F : F;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / (F / 4);
+    const int64_t c = (i % (F / 4)) * 4;
+    Vec4<T> a, o;
+    if (GLU) {
+      Vec4<T> lin;
+      lin.load(p + r * ldp + c);
+      a.load(p + r * ldp + F + c);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float l = lin.v[j], g = a.v[j];
+        if (use_limit) { l = fminf(fmaxf(l, -limit), limit); g = fminf(g, limit); }
+        if (use_extra) l = round_as<T>(l + extra);
+        o.v[j] = round_as<T>(act_apply(act, g)) * l;
+      }
+    } else {
+      a.load(p + r * ldp + c);
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = act_apply(act, a.v[j]);
+    }
+    if (thr) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        o.v[j] = rng_u32(seed, (uint64_t)(r * F + c + j)) >= thr ? round_as<T>(o.v[j]) * keep_scale : 0.f;
+    }
+    o.store(h + r * F + c);
+  }
+}
+
+template <class T, bool GLU>
+__global__ __launch_bounds__(256) void act_bwd_k(const T* __restrict__ dh, const T* __restrict__ p, T* __restrict__ dp,
+                                                 int64_t rows, int64_t F, int act, int use_limit, float limit,
+                                                 int use_extra, float extra, uint32_t thr, float keep_scale,
+                                                 uint64_t seed) {
+  const int64_t nvec = rows * (F / 4);
+  const int64_t ldp = GLU ? 2 * F : F;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / (F / 4);
+    const int64_t c = (i % (F / 4)) * 4;
+    Vec4<T> g, a;
+    g.load(dh + r * F + c);
+    if (thr) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) g.v[j] = rng_u32(seed, (uint64_t)(r * F + c + j)) >= thr ? g.v[j] * keep_scale : 0.f;
+    }
+    if (GLU) {
+      Vec4<T> lin, dl, dg;
+      lin.load(p + r * ldp + c);
+      a.load(p + r * ldp + F + c);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float l = lin.v[j], gl = a.v[j];
+        float ml = 1.f, mg = 1.f;  // clamp masks: gradient passes where the clamp is inactive
+        if (use_limit) {
+          ml = (l >= -limit && l <= limit) ? 1.f : 0.f;
+          mg = (gl <= limit) ? 1.f : 0.f;
+          l = fminf(fmaxf(l, -limit), limit);
+          gl = fminf(gl, limit);
+        }
+        if (use_extra) l = round_as<T>(l + extra);
+        dl.v[j] = g.v[j] * round_as<T>(act_apply(act, gl)) * ml;
+        dg.v[j] = g.v[j] * l * act_grad(act, gl) * mg;
+      }
+      dl.store(dp + r * ldp + c);
+      dg.store(dp + r * ldp + F + c);
+    } else {
+      a.load(p + r * ldp + c);
+      Vec4<T> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = g.v[j] * act_grad(act, a.v[j]);
+      o.store(dp + r * ldp + c);
+    }
+  }
+}
+
+static int ew_grid(int64_t nvec) {
+  int64_t g = ceil_div(nvec, 256);
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+extern "C" int vitk_act_fwd(const void* p, void* h, int dtype, int64_t rows, int64_t F, int is_glu, int act, int use_limit,
+                            float limit, int use_extra, float extra_bias, float drop_p, uint64_t seed, void* stream) {
+  VITK_REQUIRE(p && h, "act_fwd: null pointer");
+  VITK_REQUIRE(F > 0 && F % 4 == 0, "act_fwd: F=%lld must be a multiple of 4", (long long)F);
+  VITK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "act_fwd: dropout p=%f out of range", drop_p);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0;
+  const float ks = 1.f / (1.f - drop_p);
+  dim3 grid(ew_grid(rows * (F / 4))), block(256);
+  DISPATCH_DTYPE(dtype, T, {
+    if (is_glu)
+      hipLaunchKernelGGL((act_fwd_k<T, true>), grid, block, 0, st, (const T*)p, (T*)h, rows, F, act, use_limit, limit,
+                         use_extra, extra_bias, thr, ks, seed);
+    else
+      hipLaunchKernelGGL((act_fwd_k<T, false>), grid, block, 0, st, (const T*)p, (T*)h, rows, F, act, use_limit, limit,
+                         use_extra, extra_bias, thr, ks, seed);
+  });
+  VITK_LAUNCH_CHECK("act_fwd");
+  return 0;
+}
+
+extern "C" int vitk_act_bwd(const void* dh, const void* p, void* dp, int dtype, int64_t rows, int64_t F, int is_glu,
+                            int act, int use_limit, float limit, int use_extra, float extra_bias, float drop_p,
+                            uint64_t seed, void* stream) {
+  VITK_REQUIRE(dh && p && dp, "act_bwd: null pointer");
+  VITK_REQUIRE(F > 0 && F % 4 == 0, "act_bwd: F=%lld must be a multiple of 4", (long long)F);
+  VITK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "act_bwd: dropout p=%f out of range", drop_p);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0;
+  const float ks = 1.f / (1.f - drop_p);
+  dim3 grid(ew_grid(rows * (F / 4))), block(256);
+  DISPATCH_DTYPE(dtype, T, {
+    if (is_glu)
+      hipLaunchKernelGGL((act_bwd_k<T, true>), grid, block, 0, st, (const T*)dh, (const T*)p, (T*)dp, rows, F, act,
+                         use_limit, limit, use_extra, extra_bias, thr, ks, seed);
+    else
+      hipLaunchKernelGGL((act_bwd_k<T, false>), grid, block, 0, st, (const T*)dh, (const T*)p, (T*)dp, rows, F, act,
+                         use_limit, limit, use_extra, extra_bias, thr, ks, seed);
+  });
+  VITK_LAUNCH_CHECK("act_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE in place on the q and k thirds of qkv[B*S, 3*H*Dh].  One thread per (row, q|k, head, pair of
+// 2 adjacent d in the first half): reads x1 = x[d..d+1], x2 = x[d+half..], writes both.
+//   forward:  o1 = x1*cos1 - x2*sin1 ; o2 = x2*cos2 + x1*sin2
+//   inverse:  g1 = y1*cos1 + y2*sin2 ; g2 = y2*cos2 - y1*sin1     (transpose of the forward map)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const float* __restrict__ table, int64_t B,
+                                                 int64_t S, int64_t H, int64_t Dh, int64_t prefix, int inverse, int emu) {
+  const int64_t half = Dh / 2;
+  const int64_t np = half / 2;          // pairs per head
+  const int64_t N = S - prefix;         // rotated rows per sample
+  const int64_t total = B * N * 2 * H * np;
+  const float* sinT = table;
+  const float* cosT = table + N * Dh;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i;
+    const int64_t pr = t % np; t /= np;
+    const int64_t h = t % H; t /= H;
+    const int64_t which = t % 2; t /= 2;
+    const int64_t n = t % N;
+    const int64_t b = t / N;
+    const int64_t d = pr * 2;
+    T* px = qkv + ((b * S + prefix + n) * 3 + which) * (H * Dh) + h * Dh;
+    const float* ps = sinT + n * Dh;
+    const float* pc = cosT + n * Dh;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const float x1 = to_f<T>(px[d + j]), x2 = to_f<T>(px[d + j + half]);
+      const float s1 = ps[d + j], s2 = ps[d + j + half], c1 = pc[d + j], c2 = pc[d + j + half];
+      float o1, o2;
+      if (!inverse) {
+        if (emu) { o1 = round_bf16(x1 * c1) + round_bf16(-x2 * s1); o2 = round_bf16(x2 * c2) + round_bf16(x1 * s2); }
+        else { o1 = x1 * c1 - x2 * s1; o2 = x2 * c2 + x1 * s2; }
+      } else {
+        if (emu) { o1 = round_bf16(x1 * c1) + round_bf16(x2 * s2); o2 = round_bf16(x2 * c2) + round_bf16(-x1 * s1); }
+        else { o1 = x1 * c1 + x2 * s2; o2 = x2 * c2 - x1 * s1; }
+      }
+      px[d + j] = from_f<T>(o1);
+      px[d + j + half] = from_f<T>(o2);
+    }
+  }
+}
+
+extern "C" int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
+                            int64_t prefix, int inverse, int emulate_bf16, void* stream) {
+  VITK_REQUIRE(qkv && table, "rope: null pointer");
+  VITK_REQUIRE(Dh > 0 && Dh % 4 == 0, "rope: head_dim=%lld must be a multiple of 4", (long long)Dh);
+  VITK_REQUIRE(prefix >= 0 && prefix <= S, "rope: prefix=%lld outside [0, %lld]", (long long)prefix, (long long)S);
+  const int64_t total = B * (S - prefix) * 2 * H * (Dh / 4);
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_grid(total)), block(256);
+  DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((rope_qk_k<T>), grid, block, 0, st, (T*)qkv, table, B, S, H, Dh, prefix, inverse, emulate_bf16);
+  });
+  VITK_LAUNCH_CHECK("rope");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch unfolding / folding (stride == kernel, so it is a permutation plus zero padding)
+// ------------------------------------------------------------------------------------------------
+template <class TX, class TC, bool FOLD>
+__global__ __launch_bounds__(256) void im2col_k(const TX* x_in, TX* x_out, const TC* c_in, TC* c_out, int64_t B, int64_t C,
+                                                int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t ldc) {
+  const int64_t gh = H / ph, gw = W / pw, K = C * ph * pw;
+  const int64_t total = B * gh * gw * ldc;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t k = i % ldc;
+    const int64_t m = i / ldc;
+    if (k >= K) {
+      if (!FOLD) c_out[i] = from_f<TC>(0.f);
+      continue;
+    }
+    const int64_t v = k % pw, u = (k / pw) % ph, c = k / (pw * ph);
+    const int64_t j = m % gw, ii = (m / gw) % gh, b = m / (gw * gh);
+    const int64_t xi = ((b * C + c) * H + ii * ph + u) * W + j * pw + v;
+    if (FOLD) x_out[xi] = from_f<TX>(to_f<TC>(c_in[i]));
+    else c_out[i] = from_f<TC>(to_f<TX>(x_in[xi]));
+  }
+}
+
+// rows/columns of the image that no patch covers (H % ph, W % pw) get a zero gradient
+template <class TX>
+__global__ __launch_bounds__(256) void zero_uncovered_k(TX* dx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Hc,
+                                                        int64_t Wc) {
+  const int64_t total = B * C * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t w = i % W, h = (i / W) % H;
+    if (h >= Hc || w >= Wc) dx[i] = from_f<TX>(0.f);
+  }
+}
+
+extern "C" int vitk_im2col(const void* x, int x_dtype, void* cols, int cols_dtype, int64_t B, int64_t C, int64_t H,
+                           int64_t W, int64_t ph, int64_t pw, int64_t ldc, void* stream) {
+  VITK_REQUIRE(x && cols && ph > 0 && pw > 0, "im2col: bad arguments");
+  VITK_REQUIRE(ldc >= C * ph * pw, "im2col: ldc=%lld < C*ph*pw=%lld", (long long)ldc, (long long)(C * ph * pw));
+  const int64_t total = B * (H / ph) * (W / pw) * ldc;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_grid(total)), block(256);
+  DISPATCH_DTYPE(x_dtype, TX, {
+    DISPATCH_DTYPE(cols_dtype, TC, {
+      hipLaunchKernelGGL((im2col_k<TX, TC, false>), grid, block, 0, st, (const TX*)x, (TX*)nullptr, (const TC*)nullptr,
+                         (TC*)cols, B, C, H, W, ph, pw, ldc);
+    });
+  });
+  VITK_LAUNCH_CHECK("im2col");
+  return 0;
+}
+
+extern "C" int vitk_col2im(const void* cols, int cols_dtype, void* dx, int dx_dtype, int64_t B, int64_t C, int64_t H,
+                           int64_t W, int64_t ph, int64_t pw, int64_t ldc, void* stream) {
+  VITK_REQUIRE(cols && dx && ph > 0 && pw > 0, "col2im: bad arguments");
+  VITK_REQUIRE(ldc >= C * ph * pw, "col2im: ldc=%lld < C*ph*pw=%lld", (long long)ldc, (long long)(C * ph * pw));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = B * (H / ph) * (W / pw) * ldc;
+  const int64_t Hc = (H / ph) * ph, Wc = (W / pw) * pw;
+  DISPATCH_DTYPE(dx_dtype, TX, {
+    if ((Hc != H || Wc != W) && B * C * H * W > 0)
+      hipLaunchKernelGGL((zero_uncovered_k<TX>), dim3(ew_grid(B * C * H * W)), dim3(256), 0, st, (TX*)dx, B, C, H, W, Hc, Wc);
+    if (total > 0) {
+      DISPATCH_DTYPE(cols_dtype, TC, {
+        hipLaunchKernelGGL((im2col_k<TX, TC, true>), dim3(ew_grid(total)), dim3(256), 0, st, (const TX*)nullptr, (TX*)dx,
+                           (const TC*)cols, (TC*)nullptr, B, C, H, W, ph, pw, ldc);
+      });
+    }
+  });
+  VITK_LAUNCH_CHECK("col2im");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient preparation: out[r,n] = mask(r,n) * alpha * gamma[n] * g[row(r), n]
+// ------------------------------------------------------------------------------------------------
+template <class TG, class TO>
+__global__ __launch_bounds__(256) void scale_cast_k(const TG* __restrict__ g, int64_t ldg,
+                                                    const int64_t* __restrict__ row_idx, const TG* __restrict__ gamma,
+                                                    TO* __restrict__ out, int64_t rows, int64_t N, float alpha, uint32_t thr,
+                                                    float keep_scale, uint64_t seed) {
+  const int64_t nvec = rows * (N / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / (N / 4);
+    const int64_t c = (i % (N / 4)) * 4;
+    const int64_t src = row_idx ? row_idx[r] : r;
+    Vec4<TG> v;
+    v.load(g + src * ldg + c);
+    Vec4<TO> o;
+    if (gamma) {
+      Vec4<TG> gm; gm.load(gamma + c);
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = v.v[j] * gm.v[j] * alpha;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = v.v[j] * alpha;
+    }
+    if (thr) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = rng_u32(seed, (uint64_t)(r * N + c + j)) >= thr ? o.v[j] * keep_scale : 0.f;
+    }
+    o.store(out + r * N + c);
+  }
+}
+
+extern "C" int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, void* out,
+                               int out_dtype, int64_t rows, int64_t N, float alpha, float drop_p, uint64_t seed,
+                               void* stream) {
+  VITK_REQUIRE(g && out, "scale_cast: null pointer");
+  VITK_REQUIRE(N > 0 && N % 4 == 0 && ldg % 4 == 0, "scale_cast: N=%lld, ldg=%lld must be multiples of 4", (long long)N,
+               (long long)ldg);
+  VITK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "scale_cast: dropout p=%f out of range", drop_p);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0;
+  const float ks = 1.f / (1.f - drop_p);
+  dim3 grid(ew_grid(rows * (N / 4))), block(256);
+  DISPATCH_DTYPE(g_dtype, TG, {
+    DISPATCH_DTYPE(out_dtype, TO, {
+      hipLaunchKernelGGL((scale_cast_k<TG, TO>), grid, block, 0, st, (const TG*)g, ldg, row_idx, (const TG*)gamma, (TO*)out,
+                         rows, N, alpha, thr, ks, seed);
+    });
+  });
+  VITK_LAUNCH_CHECK("scale_cast");
+  return 0;
+}

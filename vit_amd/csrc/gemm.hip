@@ -1,0 +1,369 @@
+// GEMM for the ViT encoder path: C[M,N] = op(A) x op(B) with fused epilogues.
+//   * gemm_mfma_k   : bf16 operands, v_mfma_f32_32x32x16_bf16, 128x128x64 block tile, 4 waves (2x2),
+//                     each wave a 64x64 tile = 2x2 MFMA tiles.  Operands are staged global -> registers ->
+//                     LDS (the next tile's loads are issued before the current tile's MFMAs and written
+//                     after the barrier).  K-contiguous operands are read back with ds_read_b128 from rows
+//                     padded by 16 B; operands whose contraction index is the slow one (dgrad's weight,
+//                     both wgrad operands) stay in their memory layout and are read with
+//                     ds_read_b64_tr_b16 from rows padded by 64 B, so no transposed copy is ever made.
+//   * gemm_simple_k : portable scalar kernel for fp32 and for shapes the MFMA kernel rejects.
+// Both share the epilogue functors (bias / residual + layer-scale + dropout + drop-path scatter /
+// patch-embedding placement + position add).
+#include "common.h"
+
+struct Epi {
+  void* out;
+  const void* bias;
+  const void* res;
+  const void* gamma;
+  const int64_t* row_idx;
+  void* aux;
+  const void* pos;
+  int64_t ldo, N, tokens, seq, prefix;
+  uint64_t seed;
+  float alpha, keep_scale;
+  uint32_t thr;
+};
+
+template <int MODE, class TI, class TO>
+struct EpiOp {
+  static __device__ __forceinline__ void apply(const Epi& e, int64_t m, int64_t n, float acc) {
+    float v = acc;
+    if (e.bias) v += to_f<TI>(((const TI*)e.bias)[n]);
+    if (MODE == VITK_EPI_STORE) {
+      ((TO*)e.out)[m * e.ldo + n] = from_f<TO>(v);
+    } else if (MODE == VITK_EPI_RESIDUAL) {
+      v = round_as<TI>(v);  // the linear's output as the compute dtype holds it
+      if (e.thr) v = rng_u32(e.seed, (uint64_t)(m * e.N + n)) >= e.thr ? round_as<TI>(v * e.keep_scale) : 0.f;
+      if (e.aux) ((TI*)e.aux)[m * e.N + n] = from_f<TI>(v);
+      const int64_t row = e.row_idx ? e.row_idx[m] : m;
+      if (e.gamma) v = round_as<TO>(v * to_f<TO>(((const TO*)e.gamma)[n]));
+      const float r = to_f<TO>(((const TO*)e.res)[row * e.ldo + n]);
+      ((TO*)e.out)[row * e.ldo + n] = from_f<TO>(r + e.alpha * v);
+    } else {  // PATCH
+      const int64_t b = m / e.tokens, t = m % e.tokens;
+      v = round_as<TI>(v);
+      if (e.pos) v = round_as<TI>(v + to_f<TI>(((const TI*)e.pos)[t * e.N + n]));
+      ((TO*)e.out)[(b * e.seq + e.prefix + t) * e.ldo + n] = from_f<TO>(v);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// portable kernel: element (m,k) of A at A[m*sam + k*sak], element (k,n) of B at B[k*sbk + n*sbn]
+// ------------------------------------------------------------------------------------------------
+template <class TI, int MODE, class TO>
+__global__ __launch_bounds__(256) void gemm_simple_k(const TI* __restrict__ A, const TI* __restrict__ B, int64_t M,
+                                                     int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbk,
+                                                     int64_t sbn, Epi e) {
+  __shared__ float As[16][65];
+  __shared__ float Bs[16][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+  for (int64_t k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int el = tid + i * 256;
+      int kk, mm;
+      if (sak == 1) { kk = el & 15; mm = el >> 4; } else { mm = el & 63; kk = el >> 6; }
+      As[kk][mm] = (m0 + mm < M && k0 + kk < K) ? to_f<TI>(A[(m0 + mm) * sam + (k0 + kk) * sak]) : 0.f;
+      int kb, nn;
+      if (sbk == 1) { kb = el & 15; nn = el >> 4; } else { nn = el & 63; kb = el >> 6; }
+      Bs[kb][nn] = (n0 + nn < N && k0 + kb < K) ? to_f<TI>(B[(k0 + kb) * sbk + (n0 + nn) * sbn]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m < M && n < N) EpiOp<MODE, TI, TO>::apply(e, m, n, acc[i][j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int ROW_B = BK * 2 + 16;     // 144 B: K-contiguous tile [128][64] bf16, rows padded by 16 B
+constexpr int TROW_B = BM * 2 + 64;    // 320 B: contraction-major tile [64][128] bf16, rows padded by 64 B
+constexpr int TILE_B = 20480;          // max(128*144, 64*320)
+constexpr int MODE_PARTIAL = -1;       // split-K: raw fp32 accumulators to the workspace
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// fragment of the MFMA A operand (rows = M index) or B operand (cols = N index): 8 contraction values
+// k = ks*16 + 8*(lane>>5) + j for index r0 + (lane & 31).
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag(const char* s, int r0, int ks, int lane) {
+  if (!TR) {
+    return *(const bf16x8*)(s + (r0 + (lane & 31)) * ROW_B + (ks * 16 + 8 * (lane >> 5)) * 2);
+  } else {
+    const int kbase = ks * 16 + 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int col = r0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const char* p = s + kbase * TROW_B + col * 2;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * TROW_B));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+}
+
+// global -> registers for one operand tile. TR=false: rows x [k0,k0+64); TR=true: [k0,k0+64) x cols.
+template <bool TR>
+__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16* __restrict__ g, int64_t ld, int64_t row0,
+                                          int64_t nrows, int64_t k0, int64_t kend, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid + i * 256;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!TR) {
+      const int64_t row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
+      if (row < nrows && k < kend) v = *(const uint4*)(g + row * ld + k);
+    } else {
+      const int64_t k = k0 + (c >> 4), col = row0 + (c & 15) * 8;
+      if (k < kend && col < nrows) v = *(const uint4*)(g + k * ld + col);
+    }
+    r[i] = v;
+  }
+}
+template <bool TR>
+__device__ __forceinline__ void store_tile(const uint4 (&r)[4], char* s, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid + i * 256;
+    if (!TR) *(uint4*)(s + (c >> 3) * ROW_B + (c & 7) * 16) = r[i];
+    else *(uint4*)(s + (c >> 4) * TROW_B + (c & 15) * 16) = r[i];
+  }
+}
+
+// blocks that share an XCD (bid % 8) get consecutive tile ids, so one L2 sees neighbouring tiles
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
+  const int64_t xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <bool TA, bool TB, int MODE, class TO>
+__global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, const bf16* __restrict__ B, int64_t M,
+                                                   int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
+                                                   int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_B];
+  char* sA = smem;
+  char* sB = smem + TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  const int64_t m0 = tm * BM, n0 = tn * BN;
+  const int64_t kbeg = split * klen;
+  const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  load_tile<TA>(ra, A, lda, m0, M, kbeg, kend, tid);
+  load_tile<TB>(rb, B, ldb, n0, N, kbeg, kend, tid);
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    store_tile<TA>(ra, sA, tid);
+    store_tile<TB>(rb, sB, tid);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      load_tile<TA>(ra, A, lda, m0, M, k0 + BK, kend, tid);
+      load_tile<TB>(rb, B, ldb, n0, N, k0 + BK, kend, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) af[i] = read_frag<TA>(sA, wm * 64 + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; j++) bfr[j] = read_frag<TB>(sB, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // accumulator element r of lane l: row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of the 32x32 tile
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int64_t n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && n < N) {
+          if (MODE == MODE_PARTIAL) partial[(split * M + m) * N + n] = acc[i][j][r];
+          else EpiOp<(MODE < 0 ? 0 : MODE), bf16, TO>::apply(e, m, n, acc[i][j][r]);
+        }
+      }
+    }
+}
+
+template <int MODE, class TI, class TO>
+__global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ partial, int64_t M, int64_t N, int splits,
+                                                       Epi e) {
+  const int64_t total = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < splits; k++) s += partial[(int64_t)k * total + i];
+    EpiOp<MODE, TI, TO>::apply(e, i / N, i % N, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static bool mfma_ok(const VitkGemm* g) {
+  if (g->in_dtype != VITK_BF16) return false;
+  if (g->trans_a && !g->trans_b) return false;  // A^T x B^T-layout never occurs on the path
+  if (g->epilogue != VITK_EPI_STORE && (g->trans_a || g->trans_b)) return false;
+  if (!aligned16(g->a) || !aligned16(g->b)) return false;
+  if (g->lda % 8 || g->ldb % 8) return false;
+  if (!g->trans_a && g->K % 8) return false;
+  if (g->trans_a && g->M % 8) return false;
+  if (!g->trans_b && g->K % 8) return false;
+  if (g->trans_b && g->N % 8) return false;
+  return g->M > 0 && g->N > 0 && g->K > 0;
+}
+
+// split the contraction when the output has too few tiles to fill 256 CUs (weight gradients)
+static int pick_splits(const VitkGemm* g) {
+  if (g->epilogue != VITK_EPI_STORE) return 1;
+  const int64_t tiles = ceil_div(g->M, BM) * ceil_div(g->N, BN);
+  if (tiles >= 256 || g->K < 1024) return 1;
+  int64_t s = ceil_div(768, tiles);
+  const int64_t smax = g->K / 512;
+  if (s > smax) s = smax;
+  if (s > 32) s = 32;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" size_t vitk_gemm_workspace_bytes(const VitkGemm* g) {
+  if (!g || !mfma_ok(g) || g->algo == 1) return 0;
+  const int s = pick_splits(g);
+  return s > 1 ? (size_t)s * (size_t)g->M * (size_t)g->N * sizeof(float) : 0;
+}
+
+static Epi make_epi(const VitkGemm* g) {
+  Epi e;
+  e.out = g->out; e.bias = g->bias; e.res = g->res; e.gamma = g->gamma; e.row_idx = g->row_idx; e.aux = g->aux;
+  e.pos = g->pos; e.ldo = g->ldo; e.N = g->N; e.tokens = g->tokens; e.seq = g->seq; e.prefix = g->prefix;
+  e.seed = g->seed; e.alpha = g->alpha;
+  e.thr = g->drop_p > 0.f ? drop_threshold(g->drop_p) : 0;
+  e.keep_scale = 1.f / (1.f - g->drop_p);
+  return e;
+}
+
+template <class TI, class TO>
+static void launch_simple(const VitkGemm* g, const Epi& e, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(g->N, 64), (unsigned)ceil_div(g->M, 64)), block(256);
+  const int64_t sam = g->trans_a ? 1 : g->lda, sak = g->trans_a ? g->lda : 1;
+  const int64_t sbk = g->trans_b ? g->ldb : 1, sbn = g->trans_b ? 1 : g->ldb;
+#define LS(MODE)                                                                                                     \
+  hipLaunchKernelGGL((gemm_simple_k<TI, MODE, TO>), grid, block, 0, st, (const TI*)g->a, (const TI*)g->b, g->M, g->N, \
+                     g->K, sam, sak, sbk, sbn, e)
+  if (g->epilogue == VITK_EPI_STORE) LS(VITK_EPI_STORE);
+  else if (g->epilogue == VITK_EPI_RESIDUAL) LS(VITK_EPI_RESIDUAL);
+  else LS(VITK_EPI_PATCH);
+#undef LS
+}
+
+template <bool TA, bool TB, int MODE, class TO>
+static void launch_mfma_one(const VitkGemm* g, const Epi& e, int splits, int64_t klen, float* partial, hipStream_t st) {
+  const int64_t tm = ceil_div(g->M, BM), tn = ceil_div(g->N, BN);
+  dim3 grid((unsigned)(tm * tn * splits)), block(256);
+  hipLaunchKernelGGL((gemm_mfma_k<TA, TB, MODE, TO>), grid, block, 0, st, (const bf16*)g->a, (const bf16*)g->b, g->M, g->N,
+                     g->K, g->lda, g->ldb, tm, tn, klen, e, partial);
+}
+
+template <bool TA, bool TB, class TO>
+static void launch_mfma_layout(const VitkGemm* g, const Epi& e, int splits, int64_t klen, hipStream_t st) {
+  if (splits > 1) {
+    launch_mfma_one<TA, TB, MODE_PARTIAL, TO>(g, e, splits, klen, (float*)g->workspace, st);
+    const int64_t total = g->M * g->N;
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((splitk_reduce_k<VITK_EPI_STORE, bf16, TO>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       (const float*)g->workspace, g->M, g->N, splits, e);
+  } else {
+    launch_mfma_one<TA, TB, VITK_EPI_STORE, TO>(g, e, 1, klen, nullptr, st);
+  }
+}
+
+template <class TO>
+static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st) {
+  int splits = pick_splits(g);
+  if (splits > 1 && (!g->workspace || (size_t)g->workspace_bytes < (size_t)splits * g->M * g->N * sizeof(float))) splits = 1;
+  int64_t klen = ceil_div(ceil_div(g->K, splits), BK) * BK;
+  splits = (int)ceil_div(g->K, klen);
+  if (g->epilogue == VITK_EPI_RESIDUAL) launch_mfma_one<false, false, VITK_EPI_RESIDUAL, TO>(g, e, 1, klen, nullptr, st);
+  else if (g->epilogue == VITK_EPI_PATCH) launch_mfma_one<false, false, VITK_EPI_PATCH, TO>(g, e, 1, klen, nullptr, st);
+  else if (!g->trans_a && !g->trans_b) launch_mfma_layout<false, false, TO>(g, e, splits, klen, st);
+  else if (!g->trans_a && g->trans_b) launch_mfma_layout<false, true, TO>(g, e, splits, klen, st);
+  else launch_mfma_layout<true, true, TO>(g, e, splits, klen, st);
+  return 0;
+}
+
+extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
+  VITK_REQUIRE(g && g->a && g->b && g->out, "gemm: null pointer");
+  VITK_REQUIRE(g->M >= 0 && g->N > 0 && g->K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)g->M, (long long)g->N,
+               (long long)g->K);
+  VITK_REQUIRE(g->epilogue >= 0 && g->epilogue <= 2, "gemm: unknown epilogue %d", g->epilogue);
+  VITK_REQUIRE(g->in_dtype == VITK_F32 || g->in_dtype == VITK_BF16, "gemm: bad in_dtype %d", g->in_dtype);
+  VITK_REQUIRE(g->out_dtype == VITK_F32 || g->out_dtype == VITK_BF16, "gemm: bad out_dtype %d", g->out_dtype);
+  VITK_REQUIRE(!(g->in_dtype == VITK_F32 && g->out_dtype == VITK_BF16), "gemm: fp32 operands with bf16 output unsupported");
+  VITK_REQUIRE(g->drop_p >= 0.f && g->drop_p < 1.f, "gemm: dropout p=%f out of range", g->drop_p);
+  VITK_REQUIRE(g->lda >= (g->trans_a ? g->M : g->K) && g->ldb >= (g->trans_b ? g->N : g->K) && g->ldo >= g->N,
+               "gemm: leading dimension smaller than the row length");
+  if (g->epilogue == VITK_EPI_RESIDUAL) VITK_REQUIRE(g->res, "gemm: RESIDUAL epilogue needs res");
+  if (g->epilogue == VITK_EPI_PATCH)
+    VITK_REQUIRE(g->tokens > 0 && g->M % g->tokens == 0 && g->seq >= g->prefix + g->tokens,
+                 "gemm: PATCH epilogue needs tokens | M and seq >= prefix + tokens");
+  if (g->M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const Epi e = make_epi(g);
+  const bool can = mfma_ok(g);
+  VITK_REQUIRE(g->algo != 2 || can, "gemm: MFMA kernel cannot take this problem (dtype/alignment/layout)");
+  if (can && g->algo != 1) {
+    if (g->out_dtype == VITK_F32) launch_mfma<float>(g, e, st);
+    else launch_mfma<bf16>(g, e, st);
+  } else {
+    VITK_REQUIRE(ceil_div(g->M, 64) <= 65535, "gemm: M too large for the portable kernel");
+    if (g->in_dtype == VITK_F32) launch_simple<float, float>(g, e, st);
+    else if (g->out_dtype == VITK_F32) launch_simple<bf16, float>(g, e, st);
+    else launch_simple<bf16, bf16>(g, e, st);
+  }
+  VITK_LAUNCH_CHECK("gemm");
+  return 0;
+}

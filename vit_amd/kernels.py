@@ -1,0 +1,242 @@
+"""Tensor-level wrappers over the C ABI: one Python function per libvitk entry point.
+
+These check devices/contiguity, allocate outputs and workspaces with torch (PyTorch owns all device
+memory), and pass raw pointers + sizes + the current HIP stream.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+_ALGO = 0  # 0 auto, 1 portable kernels, 2 MFMA kernels (tests flip this)
+
+
+def set_algo(algo: int) -> int:
+    global _ALGO
+    old, _ALGO = _ALGO, int(algo)
+    return old
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_WS: dict = {}
+
+
+def _workspace(nbytes: int, device) -> Optional[Tensor]:
+    """Per-(device, stream) scratch, grown on demand; contents never outlive one kernel sequence."""
+    if nbytes <= 0:
+        return None
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------------------------------------
+def norm_fwd(x2: Tensor, w: Tensor, b: Optional[Tensor], eps: float, layernorm: bool, out_dtype: torch.dtype,
+             row_idx: Optional[Tensor] = None):
+    """x2 [R_in, D] -> y [rows, D], rstd [rows], mean [rows] | None.  rows = len(row_idx) or R_in."""
+    lib = L.load()
+    L.require_gpu(x2, w, b, row_idx)
+    x2 = _c(x2)
+    D = x2.shape[-1]
+    rows = x2.shape[0] if row_idx is None else row_idx.numel()
+    y = torch.empty((rows, D), dtype=out_dtype, device=x2.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x2.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x2.device) if layernorm else None
+    if b is not None and b.dtype != w.dtype:
+        b = b.to(w.dtype)
+    L.check(lib.vitk_norm_fwd(L.ptr(x2), L.dt(x2), L.ptr(_c(w)), L.ptr(None if b is None else _c(b)), L.dt(w), L.ptr(y),
+                              L.dt(y), L.ptr(rstd), L.ptr(mean), L.ptr(row_idx), rows, D, float(eps), int(layernorm),
+                              L.stream()))
+    return y, rstd, mean
+
+
+def norm_bwd(dy: Tensor, x2: Tensor, w: Tensor, rstd: Tensor, mean: Optional[Tensor], layernorm: bool,
+             add: Optional[Tensor], dx: Tensor, want_dw: bool, want_db: bool, row_idx: Optional[Tensor] = None):
+    """dx[row(r)] = (add[row(r)] if add is not None else 0) + dnorm/dx; returns (dw, db) in w.dtype."""
+    lib = L.load()
+    L.require_gpu(dy, x2, w, dx)
+    dy, x2 = _c(dy), _c(x2)
+    rows, D = dy.shape
+    assert dx.is_contiguous() and (add is None or (add.is_contiguous() and add.dtype == dx.dtype))
+    dw = torch.empty_like(w) if want_dw else None
+    db = torch.empty_like(w) if (want_db and layernorm) else None
+    ws = _workspace(lib.vitk_norm_bwd_workspace_bytes(D), dy.device) if (dw is not None or db is not None) else None
+    # the kernel computes dw and db together; ask for dw storage whenever either is wanted
+    dw_buf = dw if dw is not None else (torch.empty_like(w) if db is not None else None)
+    L.check(lib.vitk_norm_bwd(L.ptr(dy), L.dt(dy), L.ptr(x2), L.dt(x2), L.ptr(_c(w)), L.dt(w), L.ptr(rstd), L.ptr(mean),
+                              L.ptr(add), L.ptr(dx), L.dt(dx), L.ptr(dw_buf), L.ptr(db), L.ptr(row_idx), rows, D,
+                              int(layernorm), L.ptr(ws), L.stream()))
+    return dw, db
+
+
+def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, K: int, out: Tensor,
+         bias: Optional[Tensor] = None, epilogue: int = L.EPI_STORE, res: Optional[Tensor] = None,
+         gamma: Optional[Tensor] = None, row_idx: Optional[Tensor] = None, aux: Optional[Tensor] = None,
+         pos: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
+         tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None) -> Tensor:
+    lib = L.load()
+    L.require_gpu(a, b, out, bias, res, gamma, aux, pos)
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1, "gemm operands must be row-major 2-D"
+    assert a.dtype == b.dtype
+    for t in (bias, aux, pos):
+        assert t is None or (t.dtype == a.dtype and t.is_contiguous())
+    for t in (res, gamma):
+        assert t is None or (t.dtype == out.dtype and t.is_contiguous())
+    assert out.is_contiguous()
+    g = L.VitkGemm()
+    g.a, g.b, g.out = L.ptr(a), L.ptr(b), L.ptr(out)
+    g.bias, g.res, g.gamma, g.row_idx, g.aux, g.pos = (L.ptr(bias), L.ptr(res), L.ptr(gamma), L.ptr(row_idx), L.ptr(aux),
+                                                       L.ptr(pos))
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb = a.stride(0), b.stride(0)
+    g.ldo = out.shape[-1] if ldo is None else ldo
+    g.tokens, g.seq, g.prefix = tokens, seq, prefix
+    g.seed, g.alpha, g.drop_p = seed & 0xFFFFFFFFFFFFFFFF, alpha, drop_p
+    g.trans_a, g.trans_b = int(trans_a), int(trans_b)
+    g.in_dtype, g.out_dtype = L.dt(a), L.dt(out)
+    g.epilogue = epilogue
+    g.algo = _ALGO if algo is None else algo
+    g.workspace, g.workspace_bytes = None, 0
+    need = lib.vitk_gemm_workspace_bytes(C.byref(g))
+    if need:
+        ws = _workspace(need, a.device)
+        g.workspace, g.workspace_bytes = L.ptr(ws), ws.numel()
+    L.check(lib.vitk_gemm(C.byref(g), L.stream()))
+    return out
+
+
+def _attn_desc(qkv: Tensor, o: Tensor, lse: Tensor, B: int, S: int, H: int, Dh: int, scale: float, drop_p: float,
+               seed: int, algo: Optional[int]) -> L.VitkAttn:
+    """qkv is the packed projection [B*S, 3*H*Dh]; o is [B*S, H*Dh]."""
+    D = H * Dh
+    es = qkv.element_size()
+    a = L.VitkAttn()
+    base = qkv.data_ptr()
+    a.q, a.k, a.v = base, base + D * es, base + 2 * D * es
+    a.o, a.lse = L.ptr(o), L.ptr(lse)
+    a.B, a.H, a.S, a.Dh = B, H, S, Dh
+    a.q_sb, a.q_sh, a.q_ss = S * 3 * D, Dh, 3 * D
+    a.o_sb, a.o_sh, a.o_ss = S * D, Dh, D
+    a.seed, a.scale, a.drop_p = seed & 0xFFFFFFFFFFFFFFFF, scale, drop_p
+    a.dtype = L.dt(qkv)
+    a.algo = _ALGO if algo is None else algo
+    return a
+
+
+def attn_fwd(qkv: Tensor, B: int, S: int, H: int, Dh: int, scale: float, drop_p: float = 0.0, seed: int = 0,
+             algo: Optional[int] = None):
+    lib = L.load()
+    L.require_gpu(qkv)
+    assert qkv.is_contiguous() and qkv.shape == (B * S, 3 * H * Dh)
+    o = torch.empty((B * S, H * Dh), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    a = _attn_desc(qkv, o, lse, B, S, H, Dh, scale, drop_p, seed, algo)
+    L.check(lib.vitk_attn_fwd(C.byref(a), L.stream()))
+    return o, lse
+
+
+def attn_bwd(qkv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, S: int, H: int, Dh: int, scale: float,
+             drop_p: float = 0.0, seed: int = 0, algo: Optional[int] = None) -> Tensor:
+    """Returns dqkv in the packed layout of qkv."""
+    lib = L.load()
+    L.require_gpu(qkv, o, lse, dout)
+    dout = _c(dout)
+    D = H * Dh
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    a = _attn_desc(qkv, o, lse, B, S, H, Dh, scale, drop_p, seed, algo)
+    es = qkv.element_size()
+    a.dout, a.delta = L.ptr(dout), L.ptr(delta)
+    base = dqkv.data_ptr()
+    a.dq, a.dk, a.dv = base, base + D * es, base + 2 * D * es
+    a.dq_sb, a.dq_sh, a.dq_ss = S * 3 * D, Dh, 3 * D
+    L.check(lib.vitk_attn_bwd(C.byref(a), L.stream()))
+    return dqkv
+
+
+def rope_qk_(qkv: Tensor, table_f32: Tensor, B: int, S: int, H: int, Dh: int, prefix: int, inverse: bool,
+             emulate_bf16: bool) -> Tensor:
+    lib = L.load()
+    L.require_gpu(qkv, table_f32)
+    assert qkv.is_contiguous() and table_f32.is_contiguous() and table_f32.dtype == torch.float32
+    assert table_f32.shape == (2, S - prefix, Dh), f"rope table {tuple(table_f32.shape)} vs {(2, S - prefix, Dh)}"
+    L.check(lib.vitk_rope_qk(L.ptr(qkv), L.dt(qkv), L.ptr(table_f32), B, S, H, Dh, prefix, int(inverse), int(emulate_bf16),
+                             L.stream()))
+    return qkv
+
+
+def act_fwd(p: Tensor, F: int, glu: bool, act: int, limit: Optional[float], extra: Optional[float], drop_p: float,
+            seed: int) -> Tensor:
+    lib = L.load()
+    L.require_gpu(p)
+    rows = p.shape[0]
+    h = torch.empty((rows, F), dtype=p.dtype, device=p.device)
+    L.check(lib.vitk_act_fwd(L.ptr(p), L.ptr(h), L.dt(p), rows, F, int(glu), act, int(limit is not None), float(limit or 0.0),
+                             int(extra is not None), float(extra or 0.0), drop_p, seed & 0xFFFFFFFFFFFFFFFF, L.stream()))
+    return h
+
+
+def act_bwd(dh: Tensor, p: Tensor, F: int, glu: bool, act: int, limit: Optional[float], extra: Optional[float],
+            drop_p: float, seed: int) -> Tensor:
+    lib = L.load()
+    L.require_gpu(dh, p)
+    dh = _c(dh)
+    dp = torch.empty_like(p)
+    L.check(lib.vitk_act_bwd(L.ptr(dh), L.ptr(p), L.ptr(dp), L.dt(p), p.shape[0], F, int(glu), act, int(limit is not None),
+                             float(limit or 0.0), int(extra is not None), float(extra or 0.0), drop_p,
+                             seed & 0xFFFFFFFFFFFFFFFF, L.stream()))
+    return dp
+
+
+def im2col(x: Tensor, ph: int, pw: int, ldc: int, out_dtype: torch.dtype) -> Tensor:
+    lib = L.load()
+    L.require_gpu(x)
+    x = _c(x)
+    B, Cc, H, W = x.shape
+    cols = torch.empty((B * (H // ph) * (W // pw), ldc), dtype=out_dtype, device=x.device)
+    L.check(lib.vitk_im2col(L.ptr(x), L.dt(x), L.ptr(cols), L.dt(cols), B, Cc, H, W, ph, pw, ldc, L.stream()))
+    return cols
+
+
+def col2im(cols: Tensor, shape, ph: int, pw: int, out_dtype: torch.dtype) -> Tensor:
+    lib = L.load()
+    L.require_gpu(cols)
+    B, Cc, H, W = shape
+    dx = torch.empty(shape, dtype=out_dtype, device=cols.device)
+    L.check(lib.vitk_col2im(L.ptr(_c(cols)), L.dt(cols), L.ptr(dx), L.dt(dx), B, Cc, H, W, ph, pw, cols.shape[1], L.stream()))
+    return dx
+
+
+def colsum(a: Tensor, rows: int, N: int, lda: int, out_dtype: torch.dtype, *, a_idx: Optional[Tensor] = None,
+           b: Optional[Tensor] = None, ldb: int = 0, scale: float = 1.0) -> Tensor:
+    """out[n] = scale * sum_r a[ra(r)*lda + n] * (b[r*ldb + n] if b is not None else 1)."""
+    lib = L.load()
+    L.require_gpu(a, b, a_idx)
+    out = torch.empty((N,), dtype=out_dtype, device=a.device)
+    ws = _workspace(lib.vitk_colsum_workspace_bytes(N), a.device)
+    L.check(lib.vitk_colsum(L.ptr(a), L.dt(a), lda, L.ptr(a_idx), L.ptr(b), L.dt(b) if b is not None else 0, ldb, L.ptr(out),
+                            L.dt(out), rows, N, scale, L.ptr(ws), L.stream()))
+    return out
+
+
+def scale_cast(g: Tensor, rows: int, N: int, out_dtype: torch.dtype, *, row_idx: Optional[Tensor] = None,
+               gamma: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0) -> Tensor:
+    lib = L.load()
+    L.require_gpu(g, gamma, row_idx)
+    g = _c(g)
+    assert gamma is None or gamma.dtype == g.dtype
+    out = torch.empty((rows, N), dtype=out_dtype, device=g.device)
+    L.check(lib.vitk_scale_cast(L.ptr(g), L.dt(g), N, L.ptr(row_idx), L.ptr(gamma), L.ptr(out), L.dt(out), rows, N, alpha,
+                                drop_p, seed & 0xFFFFFFFFFFFFFFFF, L.stream()))
+    return out

@@ -1,0 +1,435 @@
+"""Autograd functions of the encoder hot path.  Each chains libvitk kernels in forward and backward.
+
+Dtype contract (what the reference's eager path produces, measured against it):
+  * pure mode      -- parameters and activations in one dtype T (fp32 or bf16); everything is T.
+  * autocast mode  -- fp32 master parameters under torch.autocast(bf16): linears / attention run in bf16
+                      (compute dtype TC = bf16), the residual stream, norm statistics and layer scale stay
+                      fp32 (residual dtype TR = fp32); weight gradients are produced directly in fp32.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from . import kernels as K
+
+
+# ------------------------------------------------------------------------------------------------
+# mode / rng helpers
+# ------------------------------------------------------------------------------------------------
+def compute_dtype(param_dtype: torch.dtype) -> torch.dtype:
+    """dtype the linears and attention run in for parameters of ``param_dtype`` right now."""
+    if torch.is_autocast_enabled("cuda"):
+        ac = torch.get_autocast_dtype("cuda")
+        if ac != torch.bfloat16:
+            raise NotImplementedError(f"vit_amd supports torch.autocast only with bfloat16, got {ac}")
+        return torch.bfloat16
+    if param_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"vit_amd supports float32 and bfloat16 parameters, got {param_dtype}")
+    return param_dtype
+
+
+def default_rms_eps(dtype: torch.dtype) -> float:
+    """nn.RMSNorm(eps=None): torch 2.10 resolves the default in the fp32 op-math type for fp32 and bf16 inputs."""
+    return torch.finfo(torch.float32).eps
+
+
+def next_seed(device: torch.device) -> int:
+    """A fresh 64-bit dropout stream id taken from torch's CUDA generator (no device sync).  Because it
+    advances the generator offset, torch.utils.checkpoint replays the same ids during recomputation."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    x = (gen.initial_seed() * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 29
+    return (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+
+
+def token_rows(keep_idx: Optional[Tensor], S: int) -> Optional[Tensor]:
+    """Row numbers in the flattened [B*S, D] stream of the samples selected by ``keep_idx``."""
+    if keep_idx is None:
+        return None
+    return (keep_idx.to(torch.int64)[:, None] * S + torch.arange(S, device=keep_idx.device)[None, :]).reshape(-1).contiguous()
+
+
+def _cast(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = t.detach()
+    return (t if t.dtype == dtype else t.to(dtype)).contiguous()
+
+
+def _linear_bwd(dy: Tensor, inp: Tensor, w_c: Tensor, need_dx: bool, need_dw: bool, need_db: bool, wdtype: torch.dtype,
+                dx_dtype: Optional[torch.dtype] = None):
+    """Backward of y = inp @ w^T + b.  dy [M,N], inp [M,Kin], w_c [N,Kin] (compute dtype)."""
+    M, N = dy.shape
+    Kin = inp.shape[1]
+    dx = dw = db = None
+    if need_dx:
+        dx = torch.empty((M, Kin), dtype=dx_dtype or dy.dtype, device=dy.device)
+        K.gemm(dy, w_c, trans_a=False, trans_b=True, M=M, N=Kin, K=N, out=dx)
+    if need_dw:
+        dw = torch.empty((N, Kin), dtype=wdtype, device=dy.device)
+        K.gemm(dy, inp, trans_a=True, trans_b=True, M=N, N=Kin, K=M, out=dw)
+    if need_db:
+        db = K.colsum(dy, M, N, N, wdtype)
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# apply_norm  (vit/norm.py:40-50)
+# ------------------------------------------------------------------------------------------------
+class NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, layernorm, out_dtype):
+        L.require_gpu(x, w)
+        shape = x.shape
+        x2 = x.detach().reshape(-1, shape[-1])
+        y, rstd, mean = K.norm_fwd(x2, w.detach(), None if b is None else b.detach(), eps, layernorm, out_dtype)
+        ctx.save_for_backward(x2, w, rstd, mean)
+        ctx.layernorm, ctx.shape, ctx.has_b = layernorm, shape, b is not None
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, rstd, mean = ctx.saved_tensors
+        dy2 = dy.reshape(-1, ctx.shape[-1])
+        dx = torch.empty_like(x2)
+        dw, db = K.norm_bwd(dy2, x2, w.detach(), rstd, mean, ctx.layernorm, None, dx, ctx.needs_input_grad[1],
+                            ctx.has_b and ctx.needs_input_grad[2])
+        return dx.view(ctx.shape) if ctx.needs_input_grad[0] else None, dw, db, None, None, None
+
+
+def apply_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: Optional[float], *, use_layer_norm: bool) -> Tensor:
+    """F.rms_norm / F.layer_norm over the last dim; output dtype = input dtype (as the eager ops)."""
+    if eps is None:
+        eps = 1e-5 if use_layer_norm else default_rms_eps(x.dtype)
+    return NormFn.apply(x, weight, bias, float(eps), bool(use_layer_norm), x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# generic linear  (F.linear) -- used for the Fourier position projection
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, tc):
+        L.require_gpu(x, w)
+        shape = x.shape
+        x2 = _cast(x.reshape(-1, shape[-1]), tc)
+        wc, bc = _cast(w, tc), _cast(b, tc)
+        M, Kin, N = x2.shape[0], x2.shape[1], w.shape[0]
+        y = torch.empty((M, N), dtype=tc, device=x.device)
+        K.gemm(x2, wc, trans_a=False, trans_b=False, M=M, N=N, K=Kin, out=y, bias=bc)
+        ctx.save_for_backward(x2, wc)
+        ctx.shape, ctx.xdtype, ctx.wdtype, ctx.has_b = shape, x.dtype, w.dtype, b is not None
+        return y.view(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wc = ctx.saved_tensors
+        dy2 = _cast(dy.reshape(-1, dy.shape[-1]), wc.dtype)
+        dx, dw, db = _linear_bwd(dy2, x2, wc, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                 ctx.has_b and ctx.needs_input_grad[2], ctx.wdtype)
+        if dx is not None:
+            dx = dx.view(ctx.shape).to(ctx.xdtype)
+        return dx, dw, db, None
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    return LinearFn.apply(x, w, b, compute_dtype(w.dtype))
+
+
+# ------------------------------------------------------------------------------------------------
+# residual sub-layers of the encoder block (vit/transformer.py:146-157)
+# ------------------------------------------------------------------------------------------------
+def _residual_dtype(x: Tensor, gamma: Optional[Tensor], tc: torch.dtype) -> torch.dtype:
+    t = torch.promote_types(x.dtype, tc)
+    return torch.promote_types(t, gamma.dtype) if gamma is not None else t
+
+
+def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, gamma: Optional[Tensor], rows: Optional[Tensor],
+                   alpha: float, drop_p: float, seed: int, want_aux: bool):
+    """x_new = x (+ scatter) alpha * gamma * dropout(inp @ w^T + b): the out_proj / fc2 GEMM with its fused epilogue."""
+    M, Kin = inp.shape
+    N = w_c.shape[0]
+    aux = torch.empty((M, N), dtype=inp.dtype, device=inp.device) if want_aux else None
+    if rows is None:
+        out = torch.empty_like(x2)
+        res = x2
+    else:
+        out = x2.clone()  # rows of dropped samples pass through; kept rows are updated in place
+        res = out
+    K.gemm(inp, w_c, trans_a=False, trans_b=False, M=M, N=N, K=Kin, out=out, bias=b_c, epilogue=L.EPI_RESIDUAL, res=res,
+           gamma=gamma, row_idx=rows, aux=aux, alpha=alpha, drop_p=drop_p, seed=seed)
+    return out, aux
+
+
+def _residual_grad(dnew2: Tensor, tc: torch.dtype, gamma: Optional[Tensor], rows: Optional[Tensor], nrows: int, alpha: float,
+                   drop_p: float, seed: int, aux: Optional[Tensor], need_dgamma: bool):
+    """Gradient w.r.t. the linear's output, and w.r.t. gamma."""
+    N = dnew2.shape[1]
+    dy = K.scale_cast(dnew2, nrows, N, tc, row_idx=rows, gamma=gamma, alpha=alpha, drop_p=drop_p, seed=seed)
+    dgamma = None
+    if gamma is not None and need_dgamma:
+        dgamma = K.colsum(dnew2, nrows, N, N, gamma.dtype, a_idx=rows, b=aux, ldb=N, scale=alpha)
+    return dy, dgamma
+
+
+class AttentionSublayerFn(torch.autograd.Function):
+    """x -> x (+) alpha * gamma * dropout(out_proj(SDPA(rope(qkv_proj(norm(x))))))   (vit/attention.py:163-215)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, w_qkv, b_qkv, w_out, b_out, gamma, rope, keep_idx, opt):
+        L.require_gpu(x, norm_w, w_qkv, w_out)
+        B, S, D = x.shape
+        Dh = opt["head_dim"]
+        H = D // Dh
+        tc = compute_dtype(w_qkv.dtype)
+        residual = opt["residual"]
+        tr = _residual_dtype(x, gamma, tc) if residual else tc
+        x2 = _cast(x.reshape(B * S, D), tr if residual else x.dtype)
+        rows = token_rows(keep_idx, S)
+        Bk = B if keep_idx is None else keep_idx.numel()
+        M = Bk * S
+        training = opt["training"]
+        p_attn = opt["attention_dropout"] if training else 0.0
+        p_hid = opt["dropout"] if training else 0.0
+
+        xn, rstd, mean = K.norm_fwd(x2, norm_w.detach(), None if norm_b is None else norm_b.detach(), opt["eps"],
+                                    opt["layernorm"], tc, rows)
+        wq, bq, wo, bo = _cast(w_qkv, tc), _cast(b_qkv, tc), _cast(w_out, tc), _cast(b_out, tc)
+        qkv = torch.empty((M, 3 * D), dtype=tc, device=x.device)
+        K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq)
+        table, emu = None, False
+        if rope is not None:
+            if rope.dim() != 3:
+                raise NotImplementedError("vit_amd: per-sample (masked) RoPE tables are not supported yet")
+            emu = rope.dtype == torch.bfloat16 and tc == torch.bfloat16
+            table = rope.detach().to(torch.float32).contiguous()
+            K.rope_qk_(qkv, table, Bk, S, H, Dh, S - table.shape[1], False, emu)
+        seed_a = next_seed(x.device) if p_attn > 0 else 0
+        o, lse = K.attn_fwd(qkv, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
+        seed_h = next_seed(x.device) if p_hid > 0 else 0
+        g = _cast(gamma, tr)
+        if residual:
+            out, aux = _residual_gemm(o, wo, bo, x2, g, rows, opt["alpha"], p_hid, seed_h, want_aux=g is not None)
+            y = out.view(B, S, D)
+        else:
+            zero = torch.zeros((M, D), dtype=tc, device=x.device)
+            out, aux = _residual_gemm(o, wo, bo, zero, None, None, 1.0, p_hid, seed_h, want_aux=False)
+            y = out.view(Bk, S, D)
+        ctx.save_for_backward(x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows)
+        ctx.meta = (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, x.dtype, w_qkv.dtype,
+                    norm_b is not None, b_qkv is not None, b_out is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dnew):
+        x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows = ctx.saved_tensors
+        (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, xdtype, wdtype, has_nb, has_bq,
+         has_bo) = ctx.meta
+        need = ctx.needs_input_grad
+        M = Bk * S
+        residual = opt["residual"]
+        dnew2 = _cast(dnew.reshape(-1, D), tr)
+        dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
+                                    opt["alpha"] if residual else 1.0, p_hid, seed_h, aux, need[7])
+        do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[5], has_bo and need[6], wdtype)
+        dqkv = K.attn_bwd(qkv, o, lse, do, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
+        if table is not None:
+            K.rope_qk_(dqkv, table, Bk, S, H, Dh, S - table.shape[1], True, emu)
+        dxn, dwq, dbq = _linear_bwd(dqkv, xn, wq, True, need[3], has_bq and need[4], wdtype)
+        if residual:
+            if rows is None:
+                dx = torch.empty_like(dnew2)
+                add = dnew2
+            else:
+                dx = dnew2.clone()
+                add = dx
+        else:
+            dx = torch.zeros_like(x2) if rows is not None else torch.empty_like(x2)
+            add = None
+        dnw, dnb = K.norm_bwd(dxn, x2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dx, need[1], has_nb and need[2], rows)
+        dx = dx.view(B, S, D)
+        if dx.dtype != xdtype:
+            dx = dx.to(xdtype)
+        if dgamma is not None and dgamma.dtype != g.dtype:
+            dgamma = dgamma.to(g.dtype)
+        return (dx if need[0] else None, dnw, dnb, dwq, dbq, dwo, dbo, dgamma, None, None, None)
+
+
+class MlpSublayerFn(torch.autograd.Function):
+    """x -> x (+) alpha * gamma * dropout(fc2(dropout(act(fc1(norm(x))))))   (vit/fused.py:96-166)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, w1, b1, w2, b2, gamma, keep_idx, opt):
+        L.require_gpu(x, w1, w2)
+        shape = x.shape
+        D = shape[-1]
+        S = shape[-2] if x.dim() >= 2 else 1
+        tc = compute_dtype(w1.dtype)
+        residual = opt["residual"]
+        tr = _residual_dtype(x, gamma, tc) if residual else tc
+        x2 = _cast(x.reshape(-1, D), tr if residual else x.dtype)
+        rows = token_rows(keep_idx, S)
+        M = x2.shape[0] if rows is None else rows.numel()
+        training = opt["training"]
+        p_hid = opt["dropout"] if training else 0.0
+        F1, F = w1.shape[0], w2.shape[1]
+        glu = opt["glu"]
+
+        if norm_w is not None:
+            xn, rstd, mean = K.norm_fwd(x2, norm_w.detach(), None if norm_b is None else norm_b.detach(), opt["eps"],
+                                        opt["layernorm"], tc, rows)
+        else:
+            xn, rstd, mean = _cast(x2 if rows is None else x2.index_select(0, rows), tc), None, None
+        w1c, b1c, w2c, b2c = _cast(w1, tc), _cast(b1, tc), _cast(w2, tc), _cast(b2, tc)
+        p = torch.empty((M, F1), dtype=tc, device=x.device)
+        K.gemm(xn, w1c, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=p, bias=b1c)
+        seed_1 = next_seed(x.device) if p_hid > 0 else 0
+        h = K.act_fwd(p, F, glu, opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
+        seed_2 = next_seed(x.device) if p_hid > 0 else 0
+        g = _cast(gamma, tr)
+        if residual:
+            out, aux = _residual_gemm(h, w2c, b2c, x2, g, rows, opt["alpha"], p_hid, seed_2, want_aux=g is not None)
+            y = out.view(shape)
+        else:
+            zero = torch.zeros((M, D), dtype=tc, device=x.device)
+            out, aux = _residual_gemm(h, w2c, b2c, zero, None, None, 1.0, p_hid, seed_2, want_aux=False)
+            y = out.view(*shape[:-1], D) if rows is None else out.view(-1, S, D)
+        ctx.save_for_backward(x2, norm_w, rstd, mean, xn, p, h, w1c, w2c, g, aux, rows)
+        ctx.meta = (shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, x.dtype, w1.dtype, norm_b is not None, b1 is not None,
+                    b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dnew):
+        x2, norm_w, rstd, mean, xn, p, h, w1c, w2c, g, aux, rows = ctx.saved_tensors
+        shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, xdtype, wdtype, has_nb, has_b1, has_b2 = ctx.meta
+        need = ctx.needs_input_grad
+        M = xn.shape[0]
+        residual = opt["residual"]
+        dnew2 = _cast(dnew.reshape(-1, D), tr)
+        dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
+                                    opt["alpha"] if residual else 1.0, p_hid, seed_2, aux, need[7])
+        dh, dw2, db2 = _linear_bwd(dy, h, w2c, True, need[5], has_b2 and need[6], wdtype)
+        dp = K.act_bwd(dh, p, F, opt["glu"], opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
+        dxn, dw1, db1 = _linear_bwd(dp, xn, w1c, True, need[3], has_b1 and need[4], wdtype)
+        dnw = dnb = None
+        if norm_w is not None:
+            if residual:
+                if rows is None:
+                    dx, add = torch.empty_like(dnew2), dnew2
+                else:
+                    dx = dnew2.clone()
+                    add = dx
+            else:
+                dx = torch.zeros_like(x2) if rows is not None else torch.empty_like(x2)
+                add = None
+            dnw, dnb = K.norm_bwd(dxn, x2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dx, need[1],
+                                  has_nb and need[2], rows)
+        else:
+            dx = dxn.to(x2.dtype)
+            if residual:
+                dx = dx + dnew2 if rows is None else dnew2.index_add(0, rows, dx)
+        dx = dx.view(shape)
+        if dx.dtype != xdtype:
+            dx = dx.to(xdtype)
+        if dgamma is not None and dgamma.dtype != g.dtype:
+            dgamma = dgamma.to(g.dtype)
+        return (dx if need[0] else None, dnw, dnb, dw1, db1, dw2, db2, dgamma, None, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# patch embedding: Conv2d(k = stride = patch) as im2col + GEMM, "+ pos" in the epilogue (vit/patch_embed.py:52-59)
+# ------------------------------------------------------------------------------------------------
+class PatchEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, pos):
+        L.require_gpu(x, w)
+        tc = compute_dtype(w.dtype)
+        B, Cc, H, W = x.shape
+        D, _, ph, pw = w.shape
+        gh, gw = H // ph, W // pw
+        N = gh * gw
+        Kc = Cc * ph * pw
+        Kp = (Kc + 63) // 64 * 64  # pad the contraction to the MFMA kernel's K-tile; padding columns are zero
+        cols = K.im2col(x.detach(), ph, pw, Kp, tc)
+        wc = torch.zeros((D, Kp), dtype=tc, device=x.device)
+        wc[:, :Kc] = w.detach().reshape(D, Kc)
+        bc = _cast(b, tc)
+        posc = None if pos is None else _cast(pos.reshape(N, D), tc)
+        y = torch.empty((B * N, D), dtype=tc, device=x.device)
+        K.gemm(cols, wc, trans_a=False, trans_b=False, M=B * N, N=D, K=Kp, out=y, bias=bc, epilogue=L.EPI_PATCH, pos=posc,
+               tokens=N, seq=N, prefix=0)
+        ctx.save_for_backward(cols, wc)
+        ctx.meta = (x.shape, w.shape, x.dtype, w.dtype, tc, N, Kc, Kp, b is not None, None if pos is None else (pos.shape, pos.dtype))
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, wc = ctx.saved_tensors
+        xshape, wshape, xdtype, wdtype, tc, N, Kc, Kp, has_b, posinfo = ctx.meta
+        need = ctx.needs_input_grad
+        B = xshape[0]
+        D = wshape[0]
+        dy2 = _cast(dy.reshape(B * N, D), tc)
+        dx = dw = db = dpos = None
+        dcols, dwp, db = _linear_bwd(dy2, cols, wc, need[0], need[1], has_b and need[2], wdtype)
+        if dwp is not None:
+            dw = dwp[:, :Kc].reshape(wshape).contiguous()
+        if dcols is not None:
+            dx = K.col2im(dcols, xshape, wshape[2], wshape[3], xdtype)
+        if posinfo is not None and need[3]:
+            dpos = K.colsum(dy2, B, N * D, N * D, posinfo[1]).view(posinfo[0])
+        return dx, dw, db, dpos
+
+
+def patch_embed(x: Tensor, weight: Tensor, bias: Optional[Tensor], pos: Optional[Tensor]) -> Tensor:
+    return PatchEmbedFn.apply(x, weight, bias, pos)
+
+
+# ------------------------------------------------------------------------------------------------
+# prefix tokens: cat([cls, reg, patches], dim=1)   (vit/vit.py:500-505)
+# ------------------------------------------------------------------------------------------------
+class PrefixConcatFn(torch.autograd.Function):
+    """Copies are plain device memcpys; the only arithmetic, the batch-sum of the prefix-token gradients, is a
+    libvitk column reduction."""
+
+    @staticmethod
+    def forward(ctx, cls_tokens, register_tokens, x):
+        L.require_gpu(x, cls_tokens, register_tokens)
+        B, N, D = x.shape
+        ncls, nreg = cls_tokens.shape[1], register_tokens.shape[1]
+        dtype = torch.promote_types(torch.promote_types(cls_tokens.dtype, register_tokens.dtype), x.dtype)
+        out = torch.empty((B, ncls + nreg + N, D), dtype=dtype, device=x.device)
+        if ncls:
+            out[:, :ncls].copy_(cls_tokens.detach().expand(B, -1, -1))
+        if nreg:
+            out[:, ncls:ncls + nreg].copy_(register_tokens.detach().expand(B, -1, -1))
+        out[:, ncls + nreg:].copy_(x.detach())
+        ctx.meta = (B, N, D, ncls, nreg, cls_tokens.dtype, register_tokens.dtype, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, D, ncls, nreg, cdt, rdt, xdt = ctx.meta
+        S = ncls + nreg + N
+        dout = dout.contiguous()
+        flat = dout.view(B, S * D)
+        dcls = dreg = dx = None
+        if ctx.needs_input_grad[0] and ncls:
+            dcls = K.colsum(flat, B, ncls * D, S * D, cdt).view(1, ncls, D)
+        if ctx.needs_input_grad[1] and nreg:
+            dreg = K.colsum(flat[:, ncls * D:], B, nreg * D, S * D, rdt).view(1, nreg, D)
+        if ctx.needs_input_grad[2]:
+            dx = dout[:, ncls + nreg:].to(xdt)
+        return dcls, dreg, dx
+
+
+def concat_prefix(cls_tokens: Tensor, register_tokens: Tensor, x: Tensor) -> Tensor:
+    return PrefixConcatFn.apply(cls_tokens, register_tokens, x)

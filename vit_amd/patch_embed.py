@@ -1,0 +1,41 @@
+"""Patch embedding (reference: vit/patch_embed.py:12-59).  ``self.patch`` is an nn.Conv2d used only as the
+parameter holder (state_dict keys stem.patch.weight / .bias); the convolution runs as im2col + libvitk GEMM
+with bias and the position table added in the GEMM epilogue."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from .initialization import init_conv
+from .pos_enc import create_position_encoder
+
+
+class PatchEmbed2d(nn.Module):
+    def __init__(self, in_channels: int, hidden_size: int, patch_size: Sequence[int], img_size: Sequence[int],
+                 pos_enc: str = "fourier", device=None, dtype=None):
+        super().__init__()
+        ps = tuple(patch_size)
+        self.patch = nn.Conv2d(in_channels, hidden_size, ps, stride=ps, device=device, dtype=dtype)
+        self.reset_parameters()
+        self.pos_enc = create_position_encoder(pos_enc, hidden_size, self.tokenized_size(tuple(img_size)), device=device,
+                                               dtype=dtype)
+
+    def reset_parameters(self) -> None:
+        init_conv(self.patch)
+
+    @property
+    def patch_size(self):
+        return tuple(self.patch.weight.shape[2:])
+
+    def tokenized_size(self, size: Sequence[int]):
+        return tuple(s // p for s, p in zip(size, self.patch_size))
+
+    def original_size(self, size: Sequence[int]):
+        return tuple(s * p for s, p in zip(size, self.patch_size))
+
+    def forward(self, x: Tensor) -> Tensor:
+        pos = self.pos_enc(self.tokenized_size(x.shape[2:])) if self.pos_enc is not None else None
+        return ops.patch_embed(x, self.patch.weight, self.patch.bias, pos)

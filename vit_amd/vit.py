@@ -1,0 +1,147 @@
+"""The ViT encoder (reference: vit/vit.py:254-615): same constructor, attribute tree, state_dict keys and
+forward signature; every arithmetic step of forward/backward runs in libvitk kernels.
+
+Not provided (outside the encoder hot path): heads, decoder / cross-attention factories, token masks,
+attention-weight visualisation, torchao quantization.  They raise NotImplementedError rather than fall back."""
+from __future__ import annotations
+
+from typing import Any, Optional, Sequence
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.utils.checkpoint import checkpoint
+
+from . import ops
+from .config import ViTConfig
+from .features import ViTFeatures
+from .initialization import trunc_normal_
+from .norm import make_norm
+from .patch_embed import PatchEmbed2d
+from .rope import RopePositionEmbedding
+from .transformer import TransformerEncoderLayer
+
+__all__ = ["ViT", "ViTConfig", "ViTFeatures"]
+
+
+class ViT(nn.Module):
+    def __init__(self, config: ViTConfig, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
+                 attn_quantization_config: Any = None, device: Optional[torch.device] = None):
+        super().__init__()
+        if len(config.patch_size) != 2:
+            raise NotImplementedError("vit_amd: only 2-D patch embedding is on the hot path (PatchEmbed3d is not built)")
+        if config.heads:
+            raise NotImplementedError("vit_amd: heads are downstream of the encoder hot path and are not built")
+        if any(c is not None for c in (mlp_quantization_config, qkv_quantization_config, attn_quantization_config)):
+            raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
+        kw = {"device": device, "dtype": config.dtype}
+        self._config = config
+        D = config.hidden_size
+        self.stem = PatchEmbed2d(config.in_channels, D, config.patch_size, config.img_size,
+                                 pos_enc="none" if config.pos_enc == "rope" else config.pos_enc, **kw)
+        self.patch_embed_norm = make_norm(D, config.norm_type, **kw) if config.patch_embed_normalization else None
+        self.rope = None
+        if config.pos_enc == "rope":
+            self.rope = RopePositionEmbedding(D, base=config.rope_base, num_heads=config.num_attention_heads,
+                                              rescale_coords=config.rope_rescale_coords,
+                                              shift_coords=config.rope_shift_coords,
+                                              jitter_coords=config.rope_jitter_coords, **kw)
+        self.register_tokens = nn.Parameter(torch.empty(1, config.num_register_tokens, D, **kw),
+                                            requires_grad=config.num_register_tokens > 0)
+        self.cls_tokens = nn.Parameter(torch.empty(1, config.num_cls_tokens, D, **kw),
+                                       requires_grad=config.num_cls_tokens > 0)
+        trunc_normal_(self.register_tokens)
+        trunc_normal_(self.cls_tokens)
+        self.blocks = nn.ModuleList([self.create_encoder_layer(device=device) for _ in range(config.depth)])
+        self.output_norm = make_norm(D, config.norm_type, **kw)
+        self.mlp_requires_grad_(config.mlp_requires_grad)
+        self.self_attention_requires_grad_(config.self_attention_requires_grad)
+        self.heads = nn.ModuleDict()
+
+    # ---- construction helpers ------------------------------------------------------------------
+    @property
+    def config(self) -> ViTConfig:
+        return self._config
+
+    def create_encoder_layer(self, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
+                             attn_quantization_config: Any = None, device=None, dtype=None) -> TransformerEncoderLayer:
+        c = self._config
+        return TransformerEncoderLayer(
+            c.hidden_size, c.ffn_hidden_size, c.num_attention_heads, hidden_dropout=c.hidden_dropout,
+            attention_dropout=c.attention_dropout, attention_bias=c.attention_bias, mlp_bias=c.mlp_bias,
+            activation=c.activation, norm_type=c.norm_type, qk_normalization=c.qk_normalization,
+            drop_path_rate=c.drop_path_rate, layer_scale=c.layer_scale, glu_limit=c.glu_limit,
+            glu_extra_bias=c.glu_extra_bias, mlp_quantization_config=mlp_quantization_config,
+            qkv_quantization_config=qkv_quantization_config, attn_quantization_config=attn_quantization_config,
+            device=device, dtype=c.dtype if dtype is None else dtype)
+
+    def get_block(self, i: int) -> TransformerEncoderLayer:
+        block = self.blocks[i]
+        assert isinstance(block, TransformerEncoderLayer)
+        return block
+
+    def apply_quantization(self, *configs: Any) -> None:
+        if any(c is not None for c in configs):
+            raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
+
+    def create_mask(self, *args, **kwargs):
+        raise NotImplementedError("vit_amd: token masking is not on the encoder hot path yet")
+
+    @property
+    def prefix_length(self) -> int:
+        return self._config.num_register_tokens
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def add_prefix_tokens(self, x: Tensor) -> Tensor:
+        """[B, N, D] -> [B, n_cls + n_reg + N, D], order cls, register, patches; dtype promotes like torch.cat."""
+        return ops.concat_prefix(self.cls_tokens, self.register_tokens, x)
+
+    def prepare_rope(self, tokenized_size: Sequence[int], mask: Optional[Tensor] = None,
+                     rope_seed: Optional[int] = None) -> Tensor:
+        if self.rope is None:
+            raise ValueError("RoPE is not enabled")
+        if len(tokenized_size) != 2:
+            raise ValueError(f"RoPE not supported for non-2D input, got {tokenized_size}")
+        if mask is not None:
+            raise NotImplementedError("vit_amd: token masking is not on the encoder hot path yet")
+        return self.rope(H=tokenized_size[0], W=tokenized_size[1], rope_seed=rope_seed)
+
+    def normalize_patch_embeddings(self, x: Tensor) -> Tensor:
+        return x if self.patch_embed_norm is None else self.patch_embed_norm(x)
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, rope_seed: Optional[int] = None,
+                output_norm: bool = True) -> ViTFeatures:
+        if mask is not None:
+            raise NotImplementedError("vit_amd: token masking is not on the encoder hot path yet")
+        c = self._config
+        grid = self.stem.tokenized_size(x.shape[2:])
+        x = self.stem(x)
+        x = self.normalize_patch_embeddings(x)
+        x = self.add_prefix_tokens(x)
+        rope = self.prepare_rope(grid, None, rope_seed) if self.rope is not None else None
+        for block in self.blocks:
+            assert isinstance(block, TransformerEncoderLayer)
+            if c.activation_checkpointing and self.training:
+                x = checkpoint(block, x, rope, use_reentrant=False)
+            else:
+                x = block(x, rope=rope)
+        if output_norm:
+            x = self.output_norm(x)
+        return ViTFeatures(x, c.num_register_tokens, c.num_cls_tokens, grid)
+
+    # ---- trainability switches -----------------------------------------------------------------------
+    def mlp_requires_grad_(self, requires_grad: bool = True) -> None:
+        for block in self.blocks:
+            block.mlp.requires_grad_(requires_grad)
+
+    def self_attention_requires_grad_(self, requires_grad: bool = True) -> None:
+        for block in self.blocks:
+            block.self_attention.requires_grad_(requires_grad)
+
+    def backbone_requires_grad_(self, requires_grad: bool = True) -> None:
+        self.stem.requires_grad_(requires_grad)
+        if self.patch_embed_norm is not None:
+            self.patch_embed_norm.requires_grad_(requires_grad)
+        self.blocks.requires_grad_(requires_grad)
+        self.output_norm.requires_grad_(requires_grad)
+        self.register_tokens.requires_grad_(requires_grad)

@@ -94,16 +94,31 @@ def oracle_cfg(cfg) -> "O.OracleConfig":
     return O.OracleConfig(**{k: v for k, v in cfg.__dict__.items()})
 
 
-def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_mean", grad_rtol=None, state_seed=3):
-    """Same weights, same input, same torch.manual_seed: vit_amd (HIP) vs the oracle's torch ops on the GPU."""
+def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_mean", grad_rtol=None, state_seed=3,
+                               oracle_device="cpu"):
+    """Same weights, same input: vit_amd (HIP kernels) vs the oracle's torch ops.  The oracle runs on the CPU unless
+    the case draws random numbers on the device (drop-path's randperm); then it runs on the GPU with the same
+    torch.manual_seed, with MIOpen and the fused SDPA backends switched off so it uses plain ATen math."""
     model = cfg.instantiate(device=DEV)
-    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=state_seed, device=DEV), seed=state_seed + 1)
-    model.load_state_dict(sd, strict=True)
+    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=state_seed), seed=state_seed + 1)
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, cfg.in_channels, *hw, generator=g).to(DEV, cfg.dtype)
-    out, xg, grads = run_train(model, x, autocast, 1234, loss)
-    ref = O.run_fwd_bwd(oracle_cfg(cfg), sd, x, training=True, autocast=torch.bfloat16 if autocast else None, loss=loss,
-                        seed=1234)
+    x = torch.randn(B, cfg.in_channels, *hw, generator=g).to(cfg.dtype)
+    out, xg, grads = run_train(model, x.to(DEV), autocast, 1234, loss)
+    ac = torch.bfloat16 if autocast else None
+    if oracle_device == "cpu":
+        ref = O.run_fwd_bwd(oracle_cfg(cfg), sd, x, training=True, autocast=ac, loss=loss, seed=1234)
+    else:
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+
+        old = torch.backends.cudnn.enabled
+        torch.backends.cudnn.enabled = False
+        try:
+            with sdpa_kernel(SDPBackend.MATH):
+                ref = O.run_fwd_bwd(oracle_cfg(cfg), {k: v.to(DEV) for k, v in sd.items()}, x.to(DEV), training=True,
+                                    autocast=ac, loss=loss, seed=1234)
+        finally:
+            torch.backends.cudnn.enabled = old
     assert out.dtype == ref["out"].dtype
     close(out, ref["out"], rtol, "out")
     grtol = grad_rtol or rtol
@@ -118,7 +133,7 @@ def test_drop_path_layer_scale_matches_oracle_fp32():
     cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=3, hidden_size=64, ffn_hidden_size=128,
                     num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="srelu", pos_enc="rope",
                     layer_scale=0.1, drop_path_rate=0.25, num_register_tokens=2, dtype=torch.float32)
-    compare_with_oracle_on_gpu(cfg, 8, (32, 32), False, 1e-4)
+    compare_with_oracle_on_gpu(cfg, 8, (32, 32), False, 1e-4, oracle_device="cuda")
 
 
 def test_activation_checkpointing_equals_plain_fp32():
@@ -168,7 +183,7 @@ def test_vit_h14_droppath_layerscale_ckpt_bf16_runs_and_matches_oracle():
                     ffn_hidden_size=5120, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
                     activation="srelu", pos_enc="rope", drop_path_rate=0.25, layer_scale=1.0,
                     activation_checkpointing=True, dtype=torch.bfloat16)
-    compare_with_oracle_on_gpu(cfg, 4, (224, 224), False, 3e-2, grad_rtol=8e-2)
+    compare_with_oracle_on_gpu(cfg, 4, (224, 224), False, 3e-2, grad_rtol=8e-2, oracle_device="cuda")
 
 
 def test_vit_s16_fp32_forward_config1():
@@ -176,11 +191,11 @@ def test_vit_s16_fp32_forward_config1():
     cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(224, 224), depth=12, hidden_size=384,
                     ffn_hidden_size=1536, num_attention_heads=6, dtype=torch.float32)
     model = cfg.instantiate(device=DEV).eval()
-    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=5, device=DEV), seed=6)
-    model.load_state_dict(sd)
-    x = torch.randn(8, 3, 224, 224, device=DEV)
+    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=5), seed=6)
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()})
+    x = torch.randn(8, 3, 224, 224)
     with torch.inference_mode():
-        out = model(x).dense_features
+        out = model(x.to(DEV)).dense_features
         ref = O.vit_forward(oracle_cfg(cfg), sd, x, training=False)
     close(out, ref, 1e-4, atol_scale=2.0)
 

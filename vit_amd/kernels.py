@@ -28,6 +28,16 @@ def _c(t: Tensor) -> Tensor:
 
 _WS: dict = {}
 
+# Optional per-launch timing of tagged GEMMs with HIP events on the launch stream (used by bench.py for the
+# roofline of the dominant kernel).  _EVENTS = {"tags": set[str], "pairs": {tag: [(start, end), ...]}} or None.
+_EVENTS: Optional[dict] = None
+
+
+def profile_gemms(tags) -> dict:
+    global _EVENTS
+    _EVENTS = None if tags is None else {"tags": set(tags), "pairs": {t: [] for t in tags}}
+    return _EVENTS
+
 
 def _workspace(nbytes: int, device) -> Optional[Tensor]:
     """Per-(device, stream) scratch, grown on demand; contents never outlive one kernel sequence."""
@@ -84,7 +94,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
          bias: Optional[Tensor] = None, epilogue: int = L.EPI_STORE, res: Optional[Tensor] = None,
          gamma: Optional[Tensor] = None, row_idx: Optional[Tensor] = None, aux: Optional[Tensor] = None,
          pos: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
-         tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None) -> Tensor:
+         tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None,
+         tag: str = "") -> Tensor:
     lib = L.load()
     L.require_gpu(a, b, out, bias, res, gamma, aux, pos)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1, "gemm operands must be row-major 2-D"
@@ -112,6 +123,13 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     if need:
         ws = _workspace(need, a.device)
         g.workspace, g.workspace_bytes = L.ptr(ws), ws.numel()
+    if _EVENTS is not None and tag in _EVENTS["tags"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.vitk_gemm(C.byref(g), L.stream()))
+        e1.record()
+        _EVENTS["pairs"][tag].append((e0, e1))
+        return out
     L.check(lib.vitk_gemm(C.byref(g), L.stream()))
     return out
 

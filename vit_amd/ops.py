@@ -64,17 +64,17 @@ def _cast(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
 
 
 def _linear_bwd(dy: Tensor, inp: Tensor, w_c: Tensor, need_dx: bool, need_dw: bool, need_db: bool, wdtype: torch.dtype,
-                dx_dtype: Optional[torch.dtype] = None):
+                dx_dtype: Optional[torch.dtype] = None, tag: str = ""):
     """Backward of y = inp @ w^T + b.  dy [M,N], inp [M,Kin], w_c [N,Kin] (compute dtype)."""
     M, N = dy.shape
     Kin = inp.shape[1]
     dx = dw = db = None
     if need_dx:
         dx = torch.empty((M, Kin), dtype=dx_dtype or dy.dtype, device=dy.device)
-        K.gemm(dy, w_c, trans_a=False, trans_b=True, M=M, N=Kin, K=N, out=dx)
+        K.gemm(dy, w_c, trans_a=False, trans_b=True, M=M, N=Kin, K=N, out=dx, tag=tag + ".dgrad")
     if need_dw:
         dw = torch.empty((N, Kin), dtype=wdtype, device=dy.device)
-        K.gemm(dy, inp, trans_a=True, trans_b=True, M=N, N=Kin, K=M, out=dw)
+        K.gemm(dy, inp, trans_a=True, trans_b=True, M=N, N=Kin, K=M, out=dw, tag=tag + ".wgrad")
     if need_db:
         db = K.colsum(dy, M, N, N, wdtype)
     return dx, dw, db
@@ -108,7 +108,10 @@ def apply_norm(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: Optional[
     """F.rms_norm / F.layer_norm over the last dim; output dtype = input dtype (as the eager ops)."""
     if eps is None:
         eps = 1e-5 if use_layer_norm else default_rms_eps(x.dtype)
-    return NormFn.apply(x, weight, bias, float(eps), bool(use_layer_norm), x.dtype)
+    out_dtype = x.dtype
+    if use_layer_norm and torch.is_autocast_enabled("cuda"):
+        out_dtype = torch.float32  # layer_norm is on autocast's fp32 list (rms_norm is not), measured on ROCm torch 2.10
+    return NormFn.apply(x, weight, bias, float(eps), bool(use_layer_norm), out_dtype)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -152,7 +155,7 @@ def _residual_dtype(x: Tensor, gamma: Optional[Tensor], tc: torch.dtype) -> torc
 
 
 def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, gamma: Optional[Tensor], rows: Optional[Tensor],
-                   alpha: float, drop_p: float, seed: int, want_aux: bool):
+                   alpha: float, drop_p: float, seed: int, want_aux: bool, tag: str = ""):
     """x_new = x (+ scatter) alpha * gamma * dropout(inp @ w^T + b): the out_proj / fc2 GEMM with its fused epilogue."""
     M, Kin = inp.shape
     N = w_c.shape[0]
@@ -164,7 +167,7 @@ def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, 
         out = x2.clone()  # rows of dropped samples pass through; kept rows are updated in place
         res = out
     K.gemm(inp, w_c, trans_a=False, trans_b=False, M=M, N=N, K=Kin, out=out, bias=b_c, epilogue=L.EPI_RESIDUAL, res=res,
-           gamma=gamma, row_idx=rows, aux=aux, alpha=alpha, drop_p=drop_p, seed=seed)
+           gamma=gamma, row_idx=rows, aux=aux, alpha=alpha, drop_p=drop_p, seed=seed, tag=tag)
     return out, aux
 
 
@@ -203,7 +206,7 @@ class AttentionSublayerFn(torch.autograd.Function):
                                     opt["layernorm"], tc, rows)
         wq, bq, wo, bo = _cast(w_qkv, tc), _cast(b_qkv, tc), _cast(w_out, tc), _cast(b_out, tc)
         qkv = torch.empty((M, 3 * D), dtype=tc, device=x.device)
-        K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq)
+        K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv")
         table, emu = None, False
         if rope is not None:
             if rope.dim() != 3:
@@ -216,7 +219,7 @@ class AttentionSublayerFn(torch.autograd.Function):
         seed_h = next_seed(x.device) if p_hid > 0 else 0
         g = _cast(gamma, tr)
         if residual:
-            out, aux = _residual_gemm(o, wo, bo, x2, g, rows, opt["alpha"], p_hid, seed_h, want_aux=g is not None)
+            out, aux = _residual_gemm(o, wo, bo, x2, g, rows, opt["alpha"], p_hid, seed_h, want_aux=g is not None, tag="out")
             y = out.view(B, S, D)
         else:
             zero = torch.zeros((M, D), dtype=tc, device=x.device)
@@ -238,11 +241,11 @@ class AttentionSublayerFn(torch.autograd.Function):
         dnew2 = _cast(dnew.reshape(-1, D), tr)
         dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
                                     opt["alpha"] if residual else 1.0, p_hid, seed_h, aux, need[7])
-        do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[5], has_bo and need[6], wdtype)
+        do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[5], has_bo and need[6], wdtype, tag="out")
         dqkv = K.attn_bwd(qkv, o, lse, do, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
         if table is not None:
             K.rope_qk_(dqkv, table, Bk, S, H, Dh, S - table.shape[1], True, emu)
-        dxn, dwq, dbq = _linear_bwd(dqkv, xn, wq, True, need[3], has_bq and need[4], wdtype)
+        dxn, dwq, dbq = _linear_bwd(dqkv, xn, wq, True, need[3], has_bq and need[4], wdtype, tag="qkv")
         if residual:
             if rows is None:
                 dx = torch.empty_like(dnew2)
@@ -289,13 +292,13 @@ class MlpSublayerFn(torch.autograd.Function):
             xn, rstd, mean = _cast(x2 if rows is None else x2.index_select(0, rows), tc), None, None
         w1c, b1c, w2c, b2c = _cast(w1, tc), _cast(b1, tc), _cast(w2, tc), _cast(b2, tc)
         p = torch.empty((M, F1), dtype=tc, device=x.device)
-        K.gemm(xn, w1c, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=p, bias=b1c)
+        K.gemm(xn, w1c, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=p, bias=b1c, tag="fc1")
         seed_1 = next_seed(x.device) if p_hid > 0 else 0
         h = K.act_fwd(p, F, glu, opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
         seed_2 = next_seed(x.device) if p_hid > 0 else 0
         g = _cast(gamma, tr)
         if residual:
-            out, aux = _residual_gemm(h, w2c, b2c, x2, g, rows, opt["alpha"], p_hid, seed_2, want_aux=g is not None)
+            out, aux = _residual_gemm(h, w2c, b2c, x2, g, rows, opt["alpha"], p_hid, seed_2, want_aux=g is not None, tag="fc2")
             y = out.view(shape)
         else:
             zero = torch.zeros((M, D), dtype=tc, device=x.device)
@@ -316,9 +319,9 @@ class MlpSublayerFn(torch.autograd.Function):
         dnew2 = _cast(dnew.reshape(-1, D), tr)
         dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
                                     opt["alpha"] if residual else 1.0, p_hid, seed_2, aux, need[7])
-        dh, dw2, db2 = _linear_bwd(dy, h, w2c, True, need[5], has_b2 and need[6], wdtype)
+        dh, dw2, db2 = _linear_bwd(dy, h, w2c, True, need[5], has_b2 and need[6], wdtype, tag="fc2")
         dp = K.act_bwd(dh, p, F, opt["glu"], opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
-        dxn, dw1, db1 = _linear_bwd(dp, xn, w1c, True, need[3], has_b1 and need[4], wdtype)
+        dxn, dw1, db1 = _linear_bwd(dp, xn, w1c, True, need[3], has_b1 and need[4], wdtype, tag="fc1")
         dnw = dnb = None
         if norm_w is not None:
             if residual:

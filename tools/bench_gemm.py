@@ -1,0 +1,71 @@
+"""GEMM micro-benchmark on the encoder's shapes (random bf16 data), libvitk vs torch.matmul (hipBLASLt) as a
+same-hardware reference point.  Usage: python tools/bench_gemm.py [B]"""
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vit_amd import _lib as L
+from vit_amd import kernels as K
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+M, D, F = B * 272, 768, 3072
+dev = "cuda"
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def rnd(*shape, dtype=torch.bfloat16):
+    return (torch.rand(*shape, device=dev) * 2 - 1).to(dtype)
+
+
+cases = [  # name, layout, M, N, K, epilogue, out dtype
+    ("qkv fwd", "nt", M, 3 * D, D, "store", torch.bfloat16),
+    ("fc1 fwd", "nt", M, 2 * F, D, "store", torch.bfloat16),
+    ("out fwd", "nt", M, D, D, "res", torch.float32),
+    ("fc2 fwd", "nt", M, D, F, "res", torch.float32),
+    ("fc2 dgrad", "nn", M, F, D, "store", torch.bfloat16),
+    ("fc1 dgrad", "nn", M, D, 2 * F, "store", torch.bfloat16),
+    ("qkv dgrad", "nn", M, D, 3 * D, "store", torch.bfloat16),
+    ("out dgrad", "nn", M, D, D, "store", torch.bfloat16),
+    ("fc1 wgrad", "tn", 2 * F, D, M, "store", torch.float32),
+    ("fc2 wgrad", "tn", D, F, M, "store", torch.float32),
+    ("qkv wgrad", "tn", 3 * D, D, M, "store", torch.float32),
+    ("out wgrad", "tn", D, D, M, "store", torch.float32),
+]
+tot_ms, tot_fl = 0.0, 0.0
+for name, layout, m, n, k, epi, odt in cases:
+    if layout == "nt":
+        a, b = rnd(m, k), rnd(n, k)
+        ref = lambda: torch.matmul(a, b.t())
+    elif layout == "nn":
+        a, b = rnd(m, k), rnd(k, n)
+        ref = lambda: torch.matmul(a, b)
+    else:
+        a, b = rnd(k, m), rnd(k, n)
+        ref = lambda: torch.matmul(a.t(), b)
+    out = torch.empty(m, n, device=dev, dtype=odt)
+    kw = {}
+    if epi == "res":
+        res = torch.randn(m, n, device=dev)
+        kw = dict(epilogue=L.EPI_RESIDUAL, res=res, bias=rnd(n))
+    fn = lambda: K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=m, N=n, K=k, out=out, **kw)
+    ms = timeit(fn)
+    ms_ref = timeit(ref)
+    fl = 2.0 * m * n * k
+    tot_ms += ms
+    tot_fl += fl
+    print(f"{name:10s} {layout} M={m:6d} N={n:5d} K={k:6d}  vitk {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s   torch.matmul {ms_ref:7.3f} ms {fl / ms_ref / 1e9:7.1f} TF/s", flush=True)
+print(f"sum over one layer: {tot_ms:.3f} ms, {tot_fl / tot_ms / 1e9:.1f} TF/s")

@@ -455,7 +455,20 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   load_stationary<DHP>(qf, qp, p.q_ss, qrow, qv, Dh, lane);
   load_stationary<DHP>(gf, gp, p.o_ss, qrow, qv, Dh, lane);
   const int64_t srow = (b * p.H + h) * p.S + qrow;
-  const float lse2 = qv ? p.lse[srow] * LOG2E : 0.f, delta = qv ? p.delta[srow] : 0.f;
+  const float lse2 = qv ? p.lse[srow] * LOG2E : 0.f;
+  // delta = rowsum(dO * O), computed here (each half-wave holds half of the row) and published for attn_dkdv_k,
+  // which is launched after this kernel on the same stream
+  float delta = 0.f;
+  {
+    bf16x8 of[DHP / 16];
+    load_stationary<DHP>(of, (const bf16*)p.o + b * p.o_sb + h * p.o_sh, p.o_ss, qrow, qv, Dh, lane);
+#pragma unroll
+    for (int ks = 0; ks < DHP / 16; ks++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) delta += (float)of[ks][j] * (float)gf[ks][j];
+    delta += __shfl_xor(delta, 32, 64);
+    if (qv && lane < 32) p.delta[srow] = delta;
+  }
   const float c = p.scale * LOG2E;
   const uint64_t rbase = (uint64_t)srow * p.S;
   f32x16 dqacc[DHP / 32];
@@ -685,16 +698,16 @@ extern "C" int vitk_attn_bwd(const VitkAttn* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const AttnP p = make_p(a);
   const int64_t rows = a->B * a->H * a->S;
-  if (a->dtype == VITK_F32) hipLaunchKernelGGL((attn_delta_k<float>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((attn_delta_k<bf16>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);
   const bool can = attn_mfma_ok(a, true);
   VITK_REQUIRE(a->algo != 2 || can, "attn_bwd: MFMA kernel cannot take this problem (dtype/alignment/head_dim)");
   if (can && a->algo != 1) {
     const int nw = pick_nw(a->S, a->Dh);
     dim3 grid((unsigned)ceil_div(a->S, nw * 32), (unsigned)a->H, (unsigned)a->B);
-    ATTN_DISPATCH_DH(attn_dkdv_k, a->Dh, nw, grid, p, st);
-    ATTN_DISPATCH_DH(attn_dq_k, a->Dh, nw, grid, p, st);
+    ATTN_DISPATCH_DH(attn_dq_k, a->Dh, nw, grid, p, st);    // also writes delta
+    ATTN_DISPATCH_DH(attn_dkdv_k, a->Dh, nw, grid, p, st);  // reads delta
   } else {
+    if (a->dtype == VITK_F32) hipLaunchKernelGGL((attn_delta_k<float>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_delta_k<bf16>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);
     dim3 grid((unsigned)ceil_div(a->S, 64), (unsigned)a->H, (unsigned)a->B);
     const size_t lds = (size_t)2 * PT * a->Dh * sizeof(float);
     if (a->dtype == VITK_F32) {

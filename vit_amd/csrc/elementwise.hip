@@ -197,35 +197,83 @@ __global__ __launch_bounds__(256) void colsum_k(const TA* __restrict__ a, int64_
   out[(int64_t)blockIdx.y * out_ld + n] = from_f<TO>((s0 + s1) * scale);
 }
 
+// vectorised form (N, lda, ldb multiples of 4): a block owns 256 columns x one row chunk; each lane owns 4 columns,
+// the 4 waves take interleaved rows (4 rows in flight each) and combine through LDS.
+template <class TA, class TB, class TO>
+__global__ __launch_bounds__(256) void colsum4_k(const TA* __restrict__ a, int64_t lda, const int64_t* __restrict__ a_idx,
+                                                 const TB* __restrict__ b, int64_t ldb, TO* __restrict__ out,
+                                                 int64_t out_ld, int64_t rows, int64_t N, float scale) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 256 + lane * 4;
+  const int64_t chunk = ceil_div(rows, (int64_t)gridDim.y);
+  const int64_t r0 = (int64_t)blockIdx.y * chunk;
+  const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    for (int64_t r = r0 + wid * 4; r < r1; r += 16) {
+      Vec4<TA> va[4];
+      Vec4<TB> vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (r + u < r1) {
+          const int64_t ra = a_idx ? a_idx[r + u] : r + u;
+          va[u].load(a + ra * lda + n);
+          if (b) vb[u].load(b + (r + u) * ldb + n);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (r + u < r1) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j] += b ? va[u].v[j] * vb[u].v[j] : va[u].v[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) red[wid][lane * 4 + j] = acc[j];
+  __syncthreads();
+  const int64_t nn = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (nn < N) {
+    const int t = threadIdx.x;
+    out[(int64_t)blockIdx.y * out_ld + nn] = from_f<TO>(((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) * scale);
+  }
+}
+
 static const int COLSUM_CHUNKS = 256;
 extern "C" size_t vitk_colsum_workspace_bytes(int64_t N) { return (size_t)COLSUM_CHUNKS * (size_t)N * sizeof(float); }
+
+template <class TA, class TB, class TO>
+static void colsum_one(bool vec, dim3 grid, hipStream_t st, const TA* a, int64_t lda, const int64_t* a_idx, const TB* b,
+                       int64_t ldb, TO* out, int64_t out_ld, int64_t rows, int64_t N, float scale) {
+  if (vec) hipLaunchKernelGGL((colsum4_k<TA, TB, TO>), grid, dim3(256), 0, st, a, lda, a_idx, b, ldb, out, out_ld, rows, N, scale);
+  else hipLaunchKernelGGL((colsum_k<TA, TB, TO>), grid, dim3(256), 0, st, a, lda, a_idx, b, ldb, out, out_ld, rows, N, scale);
+}
 
 template <class TA, class TB>
 static int colsum_launch(const void* a, int64_t lda, const int64_t* a_idx, const void* b, int64_t ldb, void* out,
                          int out_dtype, int64_t rows, int64_t N, float scale, void* ws, hipStream_t st) {
-  int chunks = (int)(rows < COLSUM_CHUNKS * 4 ? ceil_div(rows, 4) : COLSUM_CHUNKS);
+  const bool vec = N % 4 == 0 && lda % 4 == 0 && (!b || ldb % 4 == 0) && ((uintptr_t)a % (4 * sizeof(TA))) == 0 &&
+                   (!b || ((uintptr_t)b % (4 * sizeof(TB))) == 0);
+  const int64_t colblocks = ceil_div(N, 256);
+  int64_t chunks = 2048 / colblocks;               // enough blocks to fill the chip ...
+  if (chunks > ceil_div(rows, 64)) chunks = ceil_div(rows, 64);   // ... but at least 64 rows per chunk
+  if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
   if (chunks < 1) chunks = 1;
-  dim3 grid((unsigned)ceil_div(N, 256), (unsigned)chunks);
+  dim3 grid((unsigned)colblocks, (unsigned)chunks);
   if (chunks == 1) {
-    if (out_dtype == VITK_F32)
-      hipLaunchKernelGGL((colsum_k<TA, TB, float>), grid, dim3(256), 0, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb,
-                         (float*)out, N, rows, N, scale);
-    else
-      hipLaunchKernelGGL((colsum_k<TA, TB, bf16>), grid, dim3(256), 0, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb,
-                         (bf16*)out, N, rows, N, scale);
+    if (out_dtype == VITK_F32) colsum_one<TA, TB, float>(vec, grid, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb, (float*)out, N, rows, N, scale);
+    else colsum_one<TA, TB, bf16>(vec, grid, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb, (bf16*)out, N, rows, N, scale);
     VITK_LAUNCH_CHECK("colsum");
     return 0;
   }
   VITK_REQUIRE(ws != nullptr, "colsum: workspace required");
-  hipLaunchKernelGGL((colsum_k<TA, TB, float>), grid, dim3(256), 0, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb,
-                     (float*)ws, N, rows, N, scale);
-  dim3 grid2((unsigned)ceil_div(N, 256), 1);
-  if (out_dtype == VITK_F32)
-    hipLaunchKernelGGL((colsum_k<float, float, float>), grid2, dim3(256), 0, st, (const float*)ws, N, nullptr,
-                       (const float*)nullptr, 0, (float*)out, N, (int64_t)chunks, N, 1.f);
-  else
-    hipLaunchKernelGGL((colsum_k<float, float, bf16>), grid2, dim3(256), 0, st, (const float*)ws, N, nullptr,
-                       (const float*)nullptr, 0, (bf16*)out, N, (int64_t)chunks, N, 1.f);
+  colsum_one<TA, TB, float>(vec, grid, st, (const TA*)a, lda, a_idx, (const TB*)b, ldb, (float*)ws, N, rows, N, scale);
+  dim3 grid2((unsigned)colblocks, 1);
+  const bool vec2 = N % 4 == 0;
+  if (out_dtype == VITK_F32) colsum_one<float, float, float>(vec2, grid2, st, (const float*)ws, N, nullptr, (const float*)nullptr, 0, (float*)out, N, chunks, N, 1.f);
+  else colsum_one<float, float, bf16>(vec2, grid2, st, (const float*)ws, N, nullptr, (const float*)nullptr, 0, (bf16*)out, N, chunks, N, 1.f);
   VITK_LAUNCH_CHECK("colsum");
   return 0;
 }

@@ -62,7 +62,16 @@ int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, cons
  *   VITK_EPI_PATCH    out[(m / tokens) * seq + prefix + m % tokens, n] = acc + bias[n] + pos[m % tokens, n]
  * algo: 0 = auto, 1 = portable scalar kernel (any dtype/shape), 2 = bf16 MFMA kernel (rejects what it cannot do).
  * split-K (wgrad) partials live in `workspace` (vitk_gemm_workspace_bytes). */
-enum { VITK_EPI_STORE = 0, VITK_EPI_RESIDUAL = 1, VITK_EPI_PATCH = 2 };
+enum {
+  VITK_EPI_STORE = 0, VITK_EPI_RESIDUAL = 1, VITK_EPI_PATCH = 2,
+  /* MLP activation fused into the producing GEMM (MFMA kernel only; vit/fused.py:114-116,153-161 and their backward):
+   *   ACT  (fc1, plain)    aux[m,n] = acc + bias (pre-activation, [M,N]);  out[m,n] = dropout(act(aux))
+   *   GLU  (fc1, gated)    N = 2F: aux[M,2F] = acc + bias;  out[m,f] = dropout(act(aux[m,F+f]) * aux[m,f]), out is [M,F]
+   *   DACT (fc2 dgrad)     out[m,n] = dropmask * acc * act'(aux[m,n])
+   *   DGLU (fc2 dgrad)     N = F, aux = pre-activations [M,2F]: out[m,f] = d lin, out[m,F+f] = d gate, out is [M,2F]
+   * dropout index = m*F + f as in vitk_act_fwd/bwd, so fused and unfused paths draw the same mask. */
+  VITK_EPI_ACT = 3, VITK_EPI_GLU = 4, VITK_EPI_DACT = 5, VITK_EPI_DGLU = 6
+};
 
 typedef struct VitkGemm {
   const void* a;
@@ -87,6 +96,11 @@ typedef struct VitkGemm {
   int32_t out_dtype;     /* dtype of out, res, gamma */
   int32_t epilogue;
   int32_t algo;
+  int32_t act;           /* ACT/GLU/DACT/DGLU: activation code */
+  int32_t use_limit;     /* GLU/DGLU: clamp as vitk_act_fwd */
+  int32_t use_extra;
+  float limit;
+  float extra_bias;
 } VitkGemm;
 
 size_t vitk_gemm_workspace_bytes(const VitkGemm* g);

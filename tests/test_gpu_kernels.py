@@ -317,3 +317,40 @@ def test_colsum_and_scale_cast():
     src = torch.randn(R + 50, N, generator=g).to(DEV)
     sc = K.scale_cast(src, R, N, torch.bfloat16, row_idx=idx, gamma=gam, alpha=1.25)
     close(sc, src[idx] * gam * 1.25, 1e-2)
+
+
+@pytest.mark.parametrize("glu", [False, True])
+@pytest.mark.parametrize("name", ["silu", "srelu", "gelu"])
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_fused_activation_epilogues_equal_the_unfused_kernels(glu, name, drop):
+    """fc1 GEMM + activation (GLU pairs columns f and F+f inside one wave) and fc2 dgrad + activation backward,
+    fused in the MFMA epilogue, must reproduce GEMM -> vitk_act_fwd / vitk_act_bwd bit for bit (same dropout mask)."""
+    M, D, F = 300, 192, 160
+    F1 = 2 * F if glu else F
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(M, D, generator=g).to(DEV, torch.bfloat16)
+    w1 = (torch.randn(F1, D, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    b1 = torch.randn(F1, generator=g).to(DEV, torch.bfloat16)
+    w2 = (torch.randn(D, F, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    dy = torch.randn(M, D, generator=g).to(DEV, torch.bfloat16)
+    code = L.ACT_CODES[name]
+    limit, extra = (1.5, 0.25) if glu else (None, None)
+    # unfused
+    p_ref = torch.empty(M, F1, device=DEV, dtype=torch.bfloat16)
+    K.gemm(x, w1, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=p_ref, bias=b1, algo=2)
+    h_ref = K.act_fwd(p_ref, F, glu, code, limit, extra, drop, 77)
+    dh_ref = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    K.gemm(dy, w2, trans_a=False, trans_b=True, M=M, N=F, K=D, out=dh_ref, algo=2)
+    dp_ref = K.act_bwd(dh_ref, p_ref, F, glu, code, limit, extra, drop, 77)
+    # fused
+    p = torch.empty_like(p_ref)
+    h = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    K.gemm(x, w1, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=h, bias=b1, aux=p,
+           epilogue=L.EPI_GLU if glu else L.EPI_ACT, act=code, limit=limit, extra=extra, drop_p=drop, seed=77, algo=2)
+    dp = torch.empty_like(p_ref)
+    K.gemm(dy, w2, trans_a=False, trans_b=True, M=M, N=F, K=D, out=dp, aux=p_ref,
+           epilogue=L.EPI_DGLU if glu else L.EPI_DACT, act=code, limit=limit, extra=extra, drop_p=drop, seed=77, ldo=F1,
+           algo=2)
+    assert torch.equal(p, p_ref)
+    assert torch.equal(h, h_ref), (h.float() - h_ref.float()).abs().max()
+    assert torch.equal(dp, dp_ref), (dp.float() - dp_ref.float()).abs().max()

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitk.so")
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_RESIDUAL, EPI_PATCH = 0, 1, 2
+EPI_STORE, EPI_RESIDUAL, EPI_PATCH, EPI_ACT, EPI_GLU, EPI_DACT, EPI_DGLU = 0, 1, 2, 3, 4, 5, 6
 ACT_CODES = {"relu": 0, "reglu": 0, "silu": 1, "swiglu": 1, "gelu": 2, "geglu": 2, "srelu": 3, "openswiglu": 4}
 
 EXPORTS = [
@@ -33,6 +33,7 @@ class VitkGemm(C.Structure):
         ("seed", C.c_uint64), ("alpha", C.c_float), ("drop_p", C.c_float),
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32), ("algo", C.c_int32),
+        ("act", C.c_int32), ("use_limit", C.c_int32), ("use_extra", C.c_int32), ("limit", C.c_float), ("extra_bias", C.c_float),
     ]
 
 

@@ -23,7 +23,147 @@ struct Epi {
   uint64_t seed;
   float alpha, keep_scale;
   uint32_t thr;
+  int act, use_limit, use_extra;
+  float limit, extra;
 };
+
+constexpr int EPI_ACT = VITK_EPI_ACT, EPI_GLU = VITK_EPI_GLU, EPI_DACT = VITK_EPI_DACT, EPI_DGLU = VITK_EPI_DGLU;
+
+// Vector form used by the MFMA kernel: 4 consecutive columns n..n+3 of row m (n % 4 == 0).
+//   STORE / RESIDUAL / PATCH as EpiOp above;
+//   ACT   p = round(acc + bias) -> aux[m, n];  out[m, n] = dropout(act(p))                      (fc1, plain MLP)
+//   DACT  out[m, n] = dropmask * acc * act'(aux[m, n])                                          (fc2 dgrad, plain MLP)
+//   DGLU  acc = dh[m, f]; lin = aux[m, f], glu = aux[m, F + f];  out[m, f] = d lin, out[m, F + f] = d glu   (F = e.N)
+// (GLU forward pairs two column groups and has its own routine below.)
+template <int MODE, class TO>
+struct EpiVec {
+  static __device__ __forceinline__ void apply(const Epi& e, int64_t m, int64_t n, float (&v)[4]) {
+    typedef bf16 TI;
+    if (e.bias) {
+      Vec4<TI> b; b.load((const TI*)e.bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] += b.v[j];
+    }
+    if (MODE == VITK_EPI_STORE) {
+      Vec4<TO> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = v[j];
+      o.store((TO*)e.out + m * e.ldo + n);
+    } else if (MODE == VITK_EPI_RESIDUAL) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        v[j] = round_as<TI>(v[j]);
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
+      }
+      if (e.aux) {
+        Vec4<TI> a;
+#pragma unroll
+        for (int j = 0; j < 4; j++) a.v[j] = v[j];
+        a.store((TI*)e.aux + m * e.N + n);
+      }
+      const int64_t row = e.row_idx ? e.row_idx[m] : m;
+      if (e.gamma) {
+        Vec4<TO> g; g.load((const TO*)e.gamma + n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = round_as<TO>(v[j] * g.v[j]);
+      }
+      Vec4<TO> r; r.load((const TO*)e.res + row * e.ldo + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) r.v[j] += e.alpha * v[j];
+      r.store((TO*)e.out + row * e.ldo + n);
+    } else if (MODE == VITK_EPI_PATCH) {
+      const int64_t b = m / e.tokens, t = m % e.tokens;
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = round_as<TI>(v[j]);
+      if (e.pos) {
+        Vec4<TI> ps; ps.load((const TI*)e.pos + t * e.N + n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = round_as<TI>(v[j] + ps.v[j]);
+      }
+      Vec4<TO> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = v[j];
+      o.store((TO*)e.out + (b * e.seq + e.prefix + t) * e.ldo + n);
+    } else if (MODE == EPI_ACT) {
+      Vec4<TI> pa;
+#pragma unroll
+      for (int j = 0; j < 4; j++) pa.v[j] = v[j];
+      pa.store((TI*)e.aux + m * e.N + n);
+      Vec4<TO> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float h = act_apply(e.act, round_as<TI>(v[j]));
+        if (e.thr) h = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? round_as<TI>(h) * e.keep_scale : 0.f;
+        o.v[j] = h;
+      }
+      o.store((TO*)e.out + m * e.ldo + n);
+    } else if (MODE == EPI_DACT) {
+      Vec4<TI> pa; pa.load((const TI*)e.aux + m * e.N + n);
+      Vec4<TO> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float g = round_as<TI>(v[j]);
+        if (e.thr) g = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? g * e.keep_scale : 0.f;
+        o.v[j] = g * act_grad(e.act, pa.v[j]);
+      }
+      o.store((TO*)e.out + m * e.ldo + n);
+    } else {  // EPI_DGLU
+      const int64_t F = e.N;
+      Vec4<TI> lin, glu;
+      lin.load((const TI*)e.aux + m * 2 * F + n);
+      glu.load((const TI*)e.aux + m * 2 * F + F + n);
+      Vec4<TO> dl, dg;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float g = round_as<TI>(v[j]);
+        if (e.thr) g = rng_u32(e.seed, (uint64_t)(m * F + n + j)) >= e.thr ? g * e.keep_scale : 0.f;
+        float l = lin.v[j], gl = glu.v[j], ml = 1.f, mg = 1.f;
+        if (e.use_limit) {
+          ml = (l >= -e.limit && l <= e.limit) ? 1.f : 0.f;
+          mg = (gl <= e.limit) ? 1.f : 0.f;
+          l = fminf(fmaxf(l, -e.limit), e.limit);
+          gl = fminf(gl, e.limit);
+        }
+        if (e.use_extra) l = round_as<TI>(l + e.extra);
+        dl.v[j] = g * round_as<TI>(act_apply(e.act, gl)) * ml;
+        dg.v[j] = g * l * act_grad(e.act, gl) * mg;
+      }
+      dl.store((TO*)e.out + m * e.ldo + n);
+      dg.store((TO*)e.out + m * e.ldo + F + n);
+    }
+  }
+};
+
+// GLU forward on a pair of column groups: lin[4] = fc1 columns f..f+3, glu[4] = columns F+f..F+f+3 of row m.
+//   aux[m, f] = lin + b, aux[m, F + f] = glu + b  (pre-activations, kept for backward);  out[m, f] = dropout(act(glu) * lin)
+template <class TO>
+__device__ __forceinline__ void epi_glu(const Epi& e, int64_t m, int64_t f, float (&lin)[4], float (&glu)[4]) {
+  typedef bf16 TI;
+  const int64_t F = e.N / 2;
+  if (e.bias) {
+    Vec4<TI> bl, bg;
+    bl.load((const TI*)e.bias + f);
+    bg.load((const TI*)e.bias + F + f);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { lin[j] += bl.v[j]; glu[j] += bg.v[j]; }
+  }
+  Vec4<TI> pl, pg;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { pl.v[j] = lin[j]; pg.v[j] = glu[j]; }
+  pl.store((TI*)e.aux + m * e.N + f);
+  pg.store((TI*)e.aux + m * e.N + F + f);
+  Vec4<TO> o;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    float l = round_as<TI>(lin[j]), g = round_as<TI>(glu[j]);
+    if (e.use_limit) { l = fminf(fmaxf(l, -e.limit), e.limit); g = fminf(g, e.limit); }
+    if (e.use_extra) l = round_as<TI>(l + e.extra);
+    float h = round_as<TI>(act_apply(e.act, g)) * l;
+    if (e.thr) h = rng_u32(e.seed, (uint64_t)(m * F + f + j)) >= e.thr ? round_as<TI>(h) * e.keep_scale : 0.f;
+    o.v[j] = h;
+  }
+  o.store((TO*)e.out + m * e.ldo + f);
+}
 
 template <int MODE, class TI, class TO>
 struct EpiOp {
@@ -106,6 +246,7 @@ constexpr int ROW_B = BK * 2 + 16;     // 144 B: K-contiguous tile [128][64] bf1
 constexpr int TROW_B = BM * 2 + 64;    // 320 B: contraction-major tile [64][128] bf16, rows padded by 64 B
 constexpr int TILE_B = 20480;          // max(128*144, 64*320)
 constexpr int MODE_PARTIAL = -1;       // split-K: raw fp32 accumulators to the workspace
+constexpr int STG_LD = 68;             // epilogue staging: 32 rows x 64 floats per wave, rows padded to 68 floats
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -129,7 +270,14 @@ __device__ __forceinline__ bf16x8 read_frag(const char* s, int r0, int ks, int l
 }
 
 // global -> registers for one operand tile. TR=false: rows x [k0,k0+64); TR=true: [k0,k0+64) x cols.
-template <bool TR>
+// GLU forward: the block's 128 "virtual" fc1 columns are, per 64-column wave slice, 32 linear columns followed by
+// their 32 gate partners (weight rows F + f), so that a lane finds both halves of a pair in its own wave's tile.
+__device__ __forceinline__ int64_t glu_row(int64_t v, int64_t F) {
+  const int64_t f = (v >> 6) * 32 + (v & 31);
+  return (v & 32) ? F + f : f;
+}
+
+template <bool TR, bool GLUMAP = false>
 __device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16* __restrict__ g, int64_t ld, int64_t row0,
                                           int64_t nrows, int64_t k0, int64_t kend, int tid) {
 #pragma unroll
@@ -137,8 +285,11 @@ __device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16* __restrict_
     const int c = tid + i * 256;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (!TR) {
-      const int64_t row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
-      if (row < nrows && k < kend) v = *(const uint4*)(g + row * ld + k);
+      int64_t row = row0 + (c >> 3);
+      const int64_t k = k0 + (c & 7) * 8;
+      const bool ok = row < nrows;
+      if (GLUMAP) row = glu_row(row, nrows >> 1);
+      if (ok && k < kend) v = *(const uint4*)(g + row * ld + k);
     } else {
       const int64_t k = k0 + (c >> 4), col = row0 + (c & 15) * 8;
       if (k < kend && col < nrows) v = *(const uint4*)(g + k * ld + col);
@@ -187,14 +338,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
 
   uint4 ra[4], rb[4];
   load_tile<TA>(ra, A, lda, m0, M, kbeg, kend, tid);
-  load_tile<TB>(rb, B, ldb, n0, N, kbeg, kend, tid);
+  load_tile<TB, MODE == EPI_GLU>(rb, B, ldb, n0, N, kbeg, kend, tid);
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
     store_tile<TA>(ra, sA, tid);
     store_tile<TB>(rb, sB, tid);
     __syncthreads();
     if (k0 + BK < kend) {
       load_tile<TA>(ra, A, lda, m0, M, k0 + BK, kend, tid);
-      load_tile<TB>(rb, B, ldb, n0, N, k0 + BK, kend, tid);
+      load_tile<TB, MODE == EPI_GLU>(rb, B, ldb, n0, N, k0 + BK, kend, tid);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
@@ -211,21 +362,48 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
     __syncthreads();
   }
 
-  // accumulator element r of lane l: row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of the 32x32 tile
+  // Epilogue.  Accumulator element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of a 32x32 tile; each
+  // wave transposes 32 rows x 64 columns at a time through its own LDS slab (row stride 68 floats) so that every
+  // lane then owns 4 consecutive columns: 16-byte loads of bias/residual and 8/16-byte stores, whole 128-B lines per row.
+  float* stg = (float*)smem + wid * (32 * STG_LD);
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 2; i++) {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int64_t n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      for (int r = 0; r < 16; r++)
+        stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+    const int64_t mbase = m0 + wm * 64 + i * 32;
+    if (MODE == EPI_GLU) {
+      const int cv = lane & 7, rr = lane >> 3;
+      const int64_t f = ((n0 + wn * 64) >> 6) * 32 + 4 * cv;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int row = it * 8 + rr;
+        const int64_t m = mbase + row;
+        float lin[4], glu[4];
+        *(float4*)lin = *(const float4*)(stg + row * STG_LD + 4 * cv);
+        *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 4 * cv);
+        if (m < M && n0 + wn * 64 + 4 * cv < N) epi_glu<TO>(e, m, f, lin, glu);
+      }
+    } else {
+      const int cv = lane & 15, rr = lane >> 4;
+      const int64_t n = n0 + wn * 64 + 4 * cv;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int row = it * 4 + rr;
+        const int64_t m = mbase + row;
+        float v[4];
+        *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
         if (m < M && n < N) {
-          if (MODE == MODE_PARTIAL) partial[(split * M + m) * N + n] = acc[i][j][r];
-          else EpiOp<(MODE < 0 ? 0 : MODE), bf16, TO>::apply(e, m, n, acc[i][j][r]);
+          if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + n) = *(const float4*)v;
+          else EpiVec<(MODE < 0 ? 0 : MODE), TO>::apply(e, m, n, v);
         }
       }
     }
+    __syncthreads();
+  }
 }
 
 template <int MODE, class TI, class TO>
@@ -247,7 +425,16 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool mfma_ok(const VitkGemm* g) {
   if (g->in_dtype != VITK_BF16) return false;
   if (g->trans_a && !g->trans_b) return false;  // A^T x B^T-layout never occurs on the path
-  if (g->epilogue != VITK_EPI_STORE && (g->trans_a || g->trans_b)) return false;
+  const int ep = g->epilogue;
+  const bool nt = !g->trans_a && !g->trans_b, nn = !g->trans_a && g->trans_b;
+  if ((ep == VITK_EPI_RESIDUAL || ep == VITK_EPI_PATCH || ep == VITK_EPI_ACT || ep == VITK_EPI_GLU) && !nt) return false;
+  if ((ep == VITK_EPI_DACT || ep == VITK_EPI_DGLU) && !nn) return false;
+  if (ep == VITK_EPI_GLU && g->N % 64) return false;
+  // the epilogue moves 4 columns per lane with vector accesses
+  if (g->N % 4 || g->ldo % 4) return false;
+  if (!aligned16(g->out) || !aligned16(g->res) || !aligned16(g->aux) || !aligned16(g->bias) || !aligned16(g->gamma) ||
+      !aligned16(g->pos))
+    return false;
   if (!aligned16(g->a) || !aligned16(g->b)) return false;
   if (g->lda % 8 || g->ldb % 8) return false;
   if (!g->trans_a && g->K % 8) return false;
@@ -282,6 +469,7 @@ static Epi make_epi(const VitkGemm* g) {
   e.seed = g->seed; e.alpha = g->alpha;
   e.thr = g->drop_p > 0.f ? drop_threshold(g->drop_p) : 0;
   e.keep_scale = 1.f / (1.f - g->drop_p);
+  e.act = g->act; e.use_limit = g->use_limit; e.use_extra = g->use_extra; e.limit = g->limit; e.extra = g->extra_bias;
   return e;
 }
 
@@ -329,6 +517,10 @@ static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st) {
   splits = (int)ceil_div(g->K, klen);
   if (g->epilogue == VITK_EPI_RESIDUAL) launch_mfma_one<false, false, VITK_EPI_RESIDUAL, TO>(g, e, 1, klen, nullptr, st);
   else if (g->epilogue == VITK_EPI_PATCH) launch_mfma_one<false, false, VITK_EPI_PATCH, TO>(g, e, 1, klen, nullptr, st);
+  else if (g->epilogue == VITK_EPI_ACT) launch_mfma_one<false, false, VITK_EPI_ACT, TO>(g, e, 1, klen, nullptr, st);
+  else if (g->epilogue == VITK_EPI_GLU) launch_mfma_one<false, false, VITK_EPI_GLU, TO>(g, e, 1, klen, nullptr, st);
+  else if (g->epilogue == VITK_EPI_DACT) launch_mfma_one<false, true, VITK_EPI_DACT, TO>(g, e, 1, klen, nullptr, st);
+  else if (g->epilogue == VITK_EPI_DGLU) launch_mfma_one<false, true, VITK_EPI_DGLU, TO>(g, e, 1, klen, nullptr, st);
   else if (!g->trans_a && !g->trans_b) launch_mfma_layout<false, false, TO>(g, e, splits, klen, st);
   else if (!g->trans_a && g->trans_b) launch_mfma_layout<false, true, TO>(g, e, splits, klen, st);
   else launch_mfma_layout<true, true, TO>(g, e, splits, klen, st);
@@ -339,13 +531,17 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   VITK_REQUIRE(g && g->a && g->b && g->out, "gemm: null pointer");
   VITK_REQUIRE(g->M >= 0 && g->N > 0 && g->K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)g->M, (long long)g->N,
                (long long)g->K);
-  VITK_REQUIRE(g->epilogue >= 0 && g->epilogue <= 2, "gemm: unknown epilogue %d", g->epilogue);
+  VITK_REQUIRE(g->epilogue >= 0 && g->epilogue <= 6, "gemm: unknown epilogue %d", g->epilogue);
+  const bool fusedact = g->epilogue >= VITK_EPI_ACT;
   VITK_REQUIRE(g->in_dtype == VITK_F32 || g->in_dtype == VITK_BF16, "gemm: bad in_dtype %d", g->in_dtype);
   VITK_REQUIRE(g->out_dtype == VITK_F32 || g->out_dtype == VITK_BF16, "gemm: bad out_dtype %d", g->out_dtype);
   VITK_REQUIRE(!(g->in_dtype == VITK_F32 && g->out_dtype == VITK_BF16), "gemm: fp32 operands with bf16 output unsupported");
   VITK_REQUIRE(g->drop_p >= 0.f && g->drop_p < 1.f, "gemm: dropout p=%f out of range", g->drop_p);
-  VITK_REQUIRE(g->lda >= (g->trans_a ? g->M : g->K) && g->ldb >= (g->trans_b ? g->N : g->K) && g->ldo >= g->N,
+  const int64_t out_cols = g->epilogue == VITK_EPI_GLU ? g->N / 2 : (g->epilogue == VITK_EPI_DGLU ? 2 * g->N : g->N);
+  VITK_REQUIRE(g->lda >= (g->trans_a ? g->M : g->K) && g->ldb >= (g->trans_b ? g->N : g->K) && g->ldo >= out_cols,
                "gemm: leading dimension smaller than the row length");
+  if (fusedact) VITK_REQUIRE(g->aux && g->in_dtype == VITK_BF16 && g->out_dtype == VITK_BF16 && g->act >= 0 && g->act <= 4,
+                             "gemm: fused activation epilogues need bf16 operands/output, aux and a valid activation");
   if (g->epilogue == VITK_EPI_RESIDUAL) VITK_REQUIRE(g->res, "gemm: RESIDUAL epilogue needs res");
   if (g->epilogue == VITK_EPI_PATCH)
     VITK_REQUIRE(g->tokens > 0 && g->M % g->tokens == 0 && g->seq >= g->prefix + g->tokens,
@@ -355,6 +551,7 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   const Epi e = make_epi(g);
   const bool can = mfma_ok(g);
   VITK_REQUIRE(g->algo != 2 || can, "gemm: MFMA kernel cannot take this problem (dtype/alignment/layout)");
+  VITK_REQUIRE(!fusedact || (can && g->algo != 1), "gemm: fused activation epilogues exist in the MFMA kernel only");
   if (can && g->algo != 1) {
     if (g->out_dtype == VITK_F32) launch_mfma<float>(g, e, st);
     else launch_mfma<bf16>(g, e, st);

@@ -95,7 +95,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
          gamma: Optional[Tensor] = None, row_idx: Optional[Tensor] = None, aux: Optional[Tensor] = None,
          pos: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
          tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None,
-         tag: str = "") -> Tensor:
+         tag: str = "", act: int = 0, limit: Optional[float] = None, extra: Optional[float] = None) -> Tensor:
     lib = L.load()
     L.require_gpu(a, b, out, bias, res, gamma, aux, pos)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1, "gemm operands must be row-major 2-D"
@@ -112,6 +112,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb = a.stride(0), b.stride(0)
     g.ldo = out.shape[-1] if ldo is None else ldo
+    g.act, g.use_limit, g.use_extra = act, int(limit is not None), int(extra is not None)
+    g.limit, g.extra_bias = float(limit or 0.0), float(extra or 0.0)
     g.tokens, g.seq, g.prefix = tokens, seq, prefix
     g.seed, g.alpha, g.drop_p = seed & 0xFFFFFFFFFFFFFFFF, alpha, drop_p
     g.trans_a, g.trans_b = int(trans_a), int(trans_b)
@@ -132,6 +134,11 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
         return out
     L.check(lib.vitk_gemm(C.byref(g), L.stream()))
     return out
+
+
+def can_fuse_activation(dtype: torch.dtype, D: int, F: int) -> bool:
+    """The MFMA GEMM can apply the MLP activation (and its backward) in its epilogue for bf16 operands."""
+    return dtype == torch.bfloat16 and _ALGO != 1 and F % 32 == 0 and D % 8 == 0
 
 
 def _attn_desc(qkv: Tensor, o: Tensor, lse: Tensor, B: int, S: int, H: int, Dh: int, scale: float, drop_p: float,

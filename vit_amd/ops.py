@@ -292,9 +292,16 @@ class MlpSublayerFn(torch.autograd.Function):
             xn, rstd, mean = _cast(x2 if rows is None else x2.index_select(0, rows), tc), None, None
         w1c, b1c, w2c, b2c = _cast(w1, tc), _cast(b1, tc), _cast(w2, tc), _cast(b2, tc)
         p = torch.empty((M, F1), dtype=tc, device=x.device)
-        K.gemm(xn, w1c, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=p, bias=b1c, tag="fc1")
         seed_1 = next_seed(x.device) if p_hid > 0 else 0
-        h = K.act_fwd(p, F, glu, opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
+        fused = K.can_fuse_activation(tc, D, F)
+        if fused:  # activation (and GLU product) applied in the fc1 GEMM epilogue; p keeps the pre-activations
+            h = torch.empty((M, F), dtype=tc, device=x.device)
+            K.gemm(xn, w1c, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=h, bias=b1c, aux=p,
+                   epilogue=L.EPI_GLU if glu else L.EPI_ACT, act=opt["act"], limit=opt["limit"], extra=opt["extra_bias"],
+                   drop_p=p_hid, seed=seed_1, tag="fc1")
+        else:
+            K.gemm(xn, w1c, trans_a=False, trans_b=False, M=M, N=F1, K=D, out=p, bias=b1c, tag="fc1")
+            h = K.act_fwd(p, F, glu, opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
         seed_2 = next_seed(x.device) if p_hid > 0 else 0
         g = _cast(gamma, tr)
         if residual:
@@ -306,21 +313,28 @@ class MlpSublayerFn(torch.autograd.Function):
             y = out.view(*shape[:-1], D) if rows is None else out.view(-1, S, D)
         ctx.save_for_backward(x2, norm_w, rstd, mean, xn, p, h, w1c, w2c, g, aux, rows)
         ctx.meta = (shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, x.dtype, w1.dtype, norm_b is not None, b1 is not None,
-                    b2 is not None)
+                    b2 is not None, fused)
         return y
 
     @staticmethod
     def backward(ctx, dnew):
         x2, norm_w, rstd, mean, xn, p, h, w1c, w2c, g, aux, rows = ctx.saved_tensors
-        shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, xdtype, wdtype, has_nb, has_b1, has_b2 = ctx.meta
+        shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, xdtype, wdtype, has_nb, has_b1, has_b2, fused = ctx.meta
         need = ctx.needs_input_grad
         M = xn.shape[0]
         residual = opt["residual"]
         dnew2 = _cast(dnew.reshape(-1, D), tr)
         dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
                                     opt["alpha"] if residual else 1.0, p_hid, seed_2, aux, need[7])
-        dh, dw2, db2 = _linear_bwd(dy, h, w2c, True, need[5], has_b2 and need[6], wdtype, tag="fc2")
-        dp = K.act_bwd(dh, p, F, opt["glu"], opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
+        if fused:  # fc2 dgrad with the activation backward in its epilogue: dh never reaches memory
+            _, dw2, db2 = _linear_bwd(dy, h, w2c, False, need[5], has_b2 and need[6], wdtype, tag="fc2")
+            dp = torch.empty_like(p)
+            K.gemm(dy, w2c, trans_a=False, trans_b=True, M=M, N=F, K=D, out=dp, aux=p,
+                   epilogue=L.EPI_DGLU if opt["glu"] else L.EPI_DACT, act=opt["act"], limit=opt["limit"],
+                   extra=opt["extra_bias"], drop_p=p_hid, seed=seed_1, ldo=p.shape[1], tag="fc2.dgrad")
+        else:
+            dh, dw2, db2 = _linear_bwd(dy, h, w2c, True, need[5], has_b2 and need[6], wdtype, tag="fc2")
+            dp = K.act_bwd(dh, p, F, opt["glu"], opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
         dxn, dw1, db1 = _linear_bwd(dp, xn, w1c, True, need[3], has_b1 and need[4], wdtype, tag="fc1")
         dnw = dnb = None
         if norm_w is not None:

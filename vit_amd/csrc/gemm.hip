@@ -90,11 +90,14 @@ struct EpiVec {
       for (int j = 0; j < 4; j++) pa.v[j] = v[j];
       pa.store((TI*)e.aux + m * e.N + n);
       Vec4<TO> o;
+      ACT_SWITCH(e.act, ACT, {
+_Pragma("unroll")
+        for (int j = 0; j < 4; j++) o.v[j] = act_apply_t<ACT>(round_as<TI>(v[j]));
+      });
+      if (e.thr) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float h = act_apply(e.act, round_as<TI>(v[j]));
-        if (e.thr) h = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? round_as<TI>(h) * e.keep_scale : 0.f;
-        o.v[j] = h;
+        for (int j = 0; j < 4; j++)
+          o.v[j] = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
       }
       o.store((TO*)e.out + m * e.ldo + n);
     } else if (MODE == EPI_DACT) {
@@ -102,10 +105,13 @@ struct EpiVec {
       Vec4<TO> o;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float g = round_as<TI>(v[j]);
-        if (e.thr) g = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? g * e.keep_scale : 0.f;
-        o.v[j] = g * act_grad(e.act, pa.v[j]);
+        v[j] = round_as<TI>(v[j]);
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
       }
+      ACT_SWITCH(e.act, ACT, {
+_Pragma("unroll")
+        for (int j = 0; j < 4; j++) o.v[j] = v[j] * act_grad_t<ACT>(pa.v[j]);
+      });
       o.store((TO*)e.out + m * e.ldo + n);
     } else {  // EPI_DGLU
       const int64_t F = e.N;
@@ -115,19 +121,26 @@ struct EpiVec {
       Vec4<TO> dl, dg;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        float g = round_as<TI>(v[j]);
-        if (e.thr) g = rng_u32(e.seed, (uint64_t)(m * F + n + j)) >= e.thr ? g * e.keep_scale : 0.f;
-        float l = lin.v[j], gl = glu.v[j], ml = 1.f, mg = 1.f;
+        v[j] = round_as<TI>(v[j]);
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+        dl.v[j] = v[j];  // becomes d lin after the activation factor below
+        dg.v[j] = v[j];
         if (e.use_limit) {
-          ml = (l >= -e.limit && l <= e.limit) ? 1.f : 0.f;
-          mg = (gl <= e.limit) ? 1.f : 0.f;
-          l = fminf(fmaxf(l, -e.limit), e.limit);
-          gl = fminf(gl, e.limit);
+          const float l = lin.v[j], gl = glu.v[j];
+          dl.v[j] = (l >= -e.limit && l <= e.limit) ? dl.v[j] : 0.f;
+          dg.v[j] = (gl <= e.limit) ? dg.v[j] : 0.f;
+          lin.v[j] = fminf(fmaxf(l, -e.limit), e.limit);
+          glu.v[j] = fminf(gl, e.limit);
         }
-        if (e.use_extra) l = round_as<TI>(l + e.extra);
-        dl.v[j] = g * round_as<TI>(act_apply(e.act, gl)) * ml;
-        dg.v[j] = g * l * act_grad(e.act, gl) * mg;
+        if (e.use_extra) lin.v[j] = round_as<TI>(lin.v[j] + e.extra);
       }
+      ACT_SWITCH(e.act, ACT, {
+_Pragma("unroll")
+        for (int j = 0; j < 4; j++) {
+          dl.v[j] *= round_as<TI>(act_apply_t<ACT>(glu.v[j]));
+          dg.v[j] *= lin.v[j] * act_grad_t<ACT>(glu.v[j]);
+        }
+      });
       dl.store((TO*)e.out + m * e.ldo + n);
       dg.store((TO*)e.out + m * e.ldo + F + n);
     }
@@ -155,12 +168,19 @@ __device__ __forceinline__ void epi_glu(const Epi& e, int64_t m, int64_t f, floa
   Vec4<TO> o;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    float l = round_as<TI>(lin[j]), g = round_as<TI>(glu[j]);
-    if (e.use_limit) { l = fminf(fmaxf(l, -e.limit), e.limit); g = fminf(g, e.limit); }
-    if (e.use_extra) l = round_as<TI>(l + e.extra);
-    float h = round_as<TI>(act_apply(e.act, g)) * l;
-    if (e.thr) h = rng_u32(e.seed, (uint64_t)(m * F + f + j)) >= e.thr ? round_as<TI>(h) * e.keep_scale : 0.f;
-    o.v[j] = h;
+    lin[j] = round_as<TI>(lin[j]);
+    glu[j] = round_as<TI>(glu[j]);
+    if (e.use_limit) { lin[j] = fminf(fmaxf(lin[j], -e.limit), e.limit); glu[j] = fminf(glu[j], e.limit); }
+    if (e.use_extra) lin[j] = round_as<TI>(lin[j] + e.extra);
+  }
+  ACT_SWITCH(e.act, ACT, {
+_Pragma("unroll")
+    for (int j = 0; j < 4; j++) o.v[j] = round_as<TI>(act_apply_t<ACT>(glu[j])) * lin[j];
+  });
+  if (e.thr) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      o.v[j] = rng_u32(e.seed, (uint64_t)(m * F + f + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
   }
   o.store((TO*)e.out + m * e.ldo + f);
 }

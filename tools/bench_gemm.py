@@ -10,6 +10,8 @@ from vit_amd import _lib as L
 from vit_amd import kernels as K
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None      # run one named case only
+NOREF = os.environ.get("NOREF") == "1"                  # skip the torch.matmul comparison (for counter runs)
 M, D, F = B * 272, 768, 3072
 dev = "cuda"
 
@@ -47,6 +49,8 @@ cases = [  # name, layout, M, N, K, epilogue, out dtype
 ]
 tot_ms, tot_fl = 0.0, 0.0
 for name, layout, m, n, k, epi, odt in cases:
+    if ONLY and name != ONLY:
+        continue
     if layout == "nt":
         a, b = rnd(m, k), rnd(n, k)
         ref = lambda: torch.matmul(a, b.t())
@@ -62,8 +66,8 @@ for name, layout, m, n, k, epi, odt in cases:
         res = torch.randn(m, n, device=dev)
         kw = dict(epilogue=L.EPI_RESIDUAL, res=res, bias=rnd(n))
     fn = lambda: K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=m, N=n, K=k, out=out, **kw)
-    ms = timeit(fn)
-    ms_ref = timeit(ref)
+    ms = timeit(fn, 5 if NOREF else 20)
+    ms_ref = ms if NOREF else timeit(ref)
     fl = 2.0 * m * n * k
     tot_ms += ms
     tot_fl += fl

@@ -35,15 +35,47 @@ constexpr int EPI_ACT = VITK_EPI_ACT, EPI_GLU = VITK_EPI_GLU, EPI_DACT = VITK_EP
 //   DACT  out[m, n] = dropmask * acc * act'(aux[m, n])                                          (fc2 dgrad, plain MLP)
 //   DGLU  acc = dh[m, f]; lin = aux[m, f], glu = aux[m, F + f];  out[m, f] = d lin, out[m, F + f] = d glu   (F = e.N)
 // (GLU forward pairs two column groups and has its own routine below.)
+// Per-row operands an epilogue reads from memory (residual row, position row, saved pre-activations).  They are
+// fetched for several rows before any of them is used, so the loads overlap instead of serialising on s_waitcnt.
+template <int MODE, class TO>
+struct EpiPre {
+  float a[4], b[4];
+  int64_t row;
+};
+
 template <int MODE, class TO>
 struct EpiVec {
-  static __device__ __forceinline__ void apply(const Epi& e, int64_t m, int64_t n, float (&v)[4]) {
-    typedef bf16 TI;
-    if (e.bias) {
-      Vec4<TI> b; b.load((const TI*)e.bias + n);
+  typedef bf16 TI;
+  static __device__ __forceinline__ void prefetch(const Epi& e, int64_t m, int64_t n, EpiPre<MODE, TO>& p) {
+    if (MODE == VITK_EPI_RESIDUAL) {
+      p.row = e.row_idx ? e.row_idx[m] : m;
+      Vec4<TO> r; r.load((const TO*)e.res + p.row * e.ldo + n);
 #pragma unroll
-      for (int j = 0; j < 4; j++) v[j] += b.v[j];
+      for (int j = 0; j < 4; j++) p.a[j] = r.v[j];
+    } else if (MODE == VITK_EPI_PATCH) {
+      if (e.pos) {
+        Vec4<TI> ps; ps.load((const TI*)e.pos + (m % e.tokens) * e.N + n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) p.a[j] = ps.v[j];
+      }
+    } else if (MODE == EPI_DACT) {
+      Vec4<TI> pa; pa.load((const TI*)e.aux + m * e.N + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) p.a[j] = pa.v[j];
+    } else if (MODE == EPI_DGLU) {
+      Vec4<TI> lin, glu;
+      lin.load((const TI*)e.aux + m * 2 * e.N + n);
+      glu.load((const TI*)e.aux + m * 2 * e.N + e.N + n);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { p.a[j] = lin.v[j]; p.b[j] = glu.v[j]; }
     }
+  }
+
+  // v = accumulators of columns n..n+3 of row m; bias/gamma = this lane's 4 columns (loaded once per tile)
+  static __device__ __forceinline__ void apply(const Epi& e, int64_t m, int64_t n, float (&v)[4], const float (&bias)[4],
+                                               const float (&gamma)[4], EpiPre<MODE, TO>& p) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] += bias[j];
     if (MODE == VITK_EPI_STORE) {
       Vec4<TO> o;
 #pragma unroll
@@ -61,28 +93,23 @@ struct EpiVec {
         for (int j = 0; j < 4; j++) a.v[j] = v[j];
         a.store((TI*)e.aux + m * e.N + n);
       }
-      const int64_t row = e.row_idx ? e.row_idx[m] : m;
+      Vec4<TO> r;
       if (e.gamma) {
-        Vec4<TO> g; g.load((const TO*)e.gamma + n);
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = round_as<TO>(v[j] * g.v[j]);
+        for (int j = 0; j < 4; j++) r.v[j] = p.a[j] + e.alpha * round_as<TO>(v[j] * gamma[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[j] = p.a[j] + e.alpha * v[j];
       }
-      Vec4<TO> r; r.load((const TO*)e.res + row * e.ldo + n);
-#pragma unroll
-      for (int j = 0; j < 4; j++) r.v[j] += e.alpha * v[j];
-      r.store((TO*)e.out + row * e.ldo + n);
+      r.store((TO*)e.out + p.row * e.ldo + n);
     } else if (MODE == VITK_EPI_PATCH) {
       const int64_t b = m / e.tokens, t = m % e.tokens;
-#pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = round_as<TI>(v[j]);
-      if (e.pos) {
-        Vec4<TI> ps; ps.load((const TI*)e.pos + t * e.N + n);
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = round_as<TI>(v[j] + ps.v[j]);
-      }
       Vec4<TO> o;
 #pragma unroll
-      for (int j = 0; j < 4; j++) o.v[j] = v[j];
+      for (int j = 0; j < 4; j++) {
+        o.v[j] = round_as<TI>(v[j]);
+        if (e.pos) o.v[j] = round_as<TI>(o.v[j] + p.a[j]);
+      }
       o.store((TO*)e.out + (b * e.seq + e.prefix + t) * e.ldo + n);
     } else if (MODE == EPI_ACT) {
       Vec4<TI> pa;
@@ -91,7 +118,7 @@ struct EpiVec {
       pa.store((TI*)e.aux + m * e.N + n);
       Vec4<TO> o;
       ACT_SWITCH(e.act, ACT, {
-_Pragma("unroll")
+        _Pragma("unroll")
         for (int j = 0; j < 4; j++) o.v[j] = act_apply_t<ACT>(round_as<TI>(v[j]));
       });
       if (e.thr) {
@@ -101,7 +128,6 @@ _Pragma("unroll")
       }
       o.store((TO*)e.out + m * e.ldo + n);
     } else if (MODE == EPI_DACT) {
-      Vec4<TI> pa; pa.load((const TI*)e.aux + m * e.N + n);
       Vec4<TO> o;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -109,36 +135,33 @@ _Pragma("unroll")
         if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
       }
       ACT_SWITCH(e.act, ACT, {
-_Pragma("unroll")
-        for (int j = 0; j < 4; j++) o.v[j] = v[j] * act_grad_t<ACT>(pa.v[j]);
+        _Pragma("unroll")
+        for (int j = 0; j < 4; j++) o.v[j] = v[j] * act_grad_t<ACT>(p.a[j]);
       });
       o.store((TO*)e.out + m * e.ldo + n);
-    } else {  // EPI_DGLU
+    } else {  // EPI_DGLU: p.a = linear pre-activation, p.b = gate pre-activation
       const int64_t F = e.N;
-      Vec4<TI> lin, glu;
-      lin.load((const TI*)e.aux + m * 2 * F + n);
-      glu.load((const TI*)e.aux + m * 2 * F + F + n);
       Vec4<TO> dl, dg;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         v[j] = round_as<TI>(v[j]);
         if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
-        dl.v[j] = v[j];  // becomes d lin after the activation factor below
+        dl.v[j] = v[j];
         dg.v[j] = v[j];
         if (e.use_limit) {
-          const float l = lin.v[j], gl = glu.v[j];
+          const float l = p.a[j], gl = p.b[j];
           dl.v[j] = (l >= -e.limit && l <= e.limit) ? dl.v[j] : 0.f;
           dg.v[j] = (gl <= e.limit) ? dg.v[j] : 0.f;
-          lin.v[j] = fminf(fmaxf(l, -e.limit), e.limit);
-          glu.v[j] = fminf(gl, e.limit);
+          p.a[j] = fminf(fmaxf(l, -e.limit), e.limit);
+          p.b[j] = fminf(gl, e.limit);
         }
-        if (e.use_extra) lin.v[j] = round_as<TI>(lin.v[j] + e.extra);
+        if (e.use_extra) p.a[j] = round_as<TI>(p.a[j] + e.extra);
       }
       ACT_SWITCH(e.act, ACT, {
-_Pragma("unroll")
+        _Pragma("unroll")
         for (int j = 0; j < 4; j++) {
-          dl.v[j] *= round_as<TI>(act_apply_t<ACT>(glu.v[j]));
-          dg.v[j] *= lin.v[j] * act_grad_t<ACT>(glu.v[j]);
+          dl.v[j] *= round_as<TI>(act_apply_t<ACT>(p.b[j]));
+          dg.v[j] *= p.a[j] * act_grad_t<ACT>(p.b[j]);
         }
       });
       dl.store((TO*)e.out + m * e.ldo + n);
@@ -150,16 +173,12 @@ _Pragma("unroll")
 // GLU forward on a pair of column groups: lin[4] = fc1 columns f..f+3, glu[4] = columns F+f..F+f+3 of row m.
 //   aux[m, f] = lin + b, aux[m, F + f] = glu + b  (pre-activations, kept for backward);  out[m, f] = dropout(act(glu) * lin)
 template <class TO>
-__device__ __forceinline__ void epi_glu(const Epi& e, int64_t m, int64_t f, float (&lin)[4], float (&glu)[4]) {
+__device__ __forceinline__ void epi_glu(const Epi& e, int64_t m, int64_t f, float (&lin)[4], float (&glu)[4],
+                                        const float (&bl)[4], const float (&bg)[4]) {
   typedef bf16 TI;
   const int64_t F = e.N / 2;
-  if (e.bias) {
-    Vec4<TI> bl, bg;
-    bl.load((const TI*)e.bias + f);
-    bg.load((const TI*)e.bias + F + f);
 #pragma unroll
-    for (int j = 0; j < 4; j++) { lin[j] += bl.v[j]; glu[j] += bg.v[j]; }
-  }
+  for (int j = 0; j < 4; j++) { lin[j] += bl[j]; glu[j] += bg[j]; }
   Vec4<TI> pl, pg;
 #pragma unroll
   for (int j = 0; j < 4; j++) { pl.v[j] = lin[j]; pg.v[j] = glu[j]; }
@@ -297,26 +316,65 @@ __device__ __forceinline__ int64_t glu_row(int64_t v, int64_t F) {
   return (v & 32) ? F + f : f;
 }
 
-template <bool TR, bool GLUMAP = false>
-__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16* __restrict__ g, int64_t ld, int64_t row0,
-                                          int64_t nrows, int64_t k0, int64_t kend, int tid) {
+// Operand tiles are fetched with buffer loads: rows/columns outside the matrix are given an out-of-range offset and
+// come back as zeros, with no branch around the load.  voff = this thread's 4 chunk offsets (bytes) at the first
+// K-step, or OOB when the chunk's row (K-contiguous operand) / column (contraction-major operand) is outside.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr uint32_t OOB = 0xffffffffu;
+
+struct TileSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[4];
+  int32_t klim[4];   // K-contiguous operand: chunk valid while (k0 - kbeg) < klim
+  uint32_t kstride;  // bytes per unit of k
+};
+
+__device__ __forceinline__ uint32_t clip32(int64_t v) { return v > 0xfffffff0ll ? 0xfffffff0u : (uint32_t)v; }
+
+template <bool TR, bool GLUMAP>
+__device__ __forceinline__ TileSrc make_src(const bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t nrows,
+                                            int64_t kbeg, int64_t kend, int64_t Ktot, int tid) {
+  TileSrc t;
+  if (!TR) {
+    const int64_t base_row = GLUMAP ? 0 : row0;
+    const int64_t span_rows = GLUMAP ? nrows : (nrows - row0 < 128 ? nrows - row0 : 128);
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + base_row * ld), 0, clip32(((span_rows - 1) * ld + Ktot) * 2), 0x00020000);
+    t.kstride = 2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + i * 256;
+      const int64_t r = row0 + (c >> 3);
+      const int64_t rr = GLUMAP ? glu_row(r, nrows >> 1) : (int64_t)(c >> 3);
+      t.voff[i] = r < nrows ? (uint32_t)((rr * ld + kbeg + (c & 7) * 8) * 2) : OOB;
+      t.klim[i] = (int32_t)(kend - kbeg) - (c & 7) * 8;
+    }
+  } else {
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + kbeg * ld + row0), 0,
+                                               clip32(((kend - kbeg - 1) * ld + (nrows - row0)) * 2), 0x00020000);
+    t.kstride = (uint32_t)(ld * 2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + i * 256;
+      const int64_t col = row0 + (c & 15) * 8;
+      t.voff[i] = col < nrows ? (uint32_t)(((int64_t)(c >> 4) * ld + (c & 15) * 8) * 2) : OOB;
+      t.klim[i] = 0x7fffffff;
+    }
+  }
+  return t;
+}
+
+// kk = k0 - kbeg (multiple of BK)
+template <bool TR>
+__device__ __forceinline__ void load_tile(uint4 (&r)[4], const TileSrc& t, int32_t kk) {
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int c = tid + i * 256;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (!TR) {
-      int64_t row = row0 + (c >> 3);
-      const int64_t k = k0 + (c & 7) * 8;
-      const bool ok = row < nrows;
-      if (GLUMAP) row = glu_row(row, nrows >> 1);
-      if (ok && k < kend) v = *(const uint4*)(g + row * ld + k);
-    } else {
-      const int64_t k = k0 + (c >> 4), col = row0 + (c & 15) * 8;
-      if (k < kend && col < nrows) v = *(const uint4*)(g + k * ld + col);
-    }
-    r[i] = v;
+    uint32_t off = t.voff[i] + (uint32_t)kk * t.kstride;
+    if (!TR) off = (kk < t.klim[i] && t.voff[i] != OOB) ? off : OOB;
+    else off = t.voff[i] != OOB ? off : OOB;
+    r[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, off, 0, 0));
   }
 }
+
 template <bool TR>
 __device__ __forceinline__ void store_tile(const uint4 (&r)[4], char* s, int tid) {
 #pragma unroll
@@ -356,16 +414,19 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  const TileSrc srcA = make_src<TA, false>(A, lda, m0, M, kbeg, kend, K, tid);
+  const TileSrc srcB = make_src<TB, MODE == EPI_GLU>(B, ldb, n0, N, kbeg, kend, K, tid);
+  const int32_t klen_here = (int32_t)(kend - kbeg);
   uint4 ra[4], rb[4];
-  load_tile<TA>(ra, A, lda, m0, M, kbeg, kend, tid);
-  load_tile<TB, MODE == EPI_GLU>(rb, B, ldb, n0, N, kbeg, kend, tid);
-  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+  load_tile<TA>(ra, srcA, 0);
+  load_tile<TB>(rb, srcB, 0);
+  for (int32_t kk = 0; kk < klen_here; kk += BK) {
     store_tile<TA>(ra, sA, tid);
     store_tile<TB>(rb, sB, tid);
     __syncthreads();
-    if (k0 + BK < kend) {
-      load_tile<TA>(ra, A, lda, m0, M, k0 + BK, kend, tid);
-      load_tile<TB, MODE == EPI_GLU>(rb, B, ldb, n0, N, k0 + BK, kend, tid);
+    if (kk + BK < klen_here) {
+      load_tile<TA>(ra, srcA, kk + BK);
+      load_tile<TB>(rb, srcB, kk + BK);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
@@ -386,6 +447,35 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
   // wave transposes 32 rows x 64 columns at a time through its own LDS slab (row stride 68 floats) so that every
   // lane then owns 4 consecutive columns: 16-byte loads of bias/residual and 8/16-byte stores, whole 128-B lines per row.
   float* stg = (float*)smem + wid * (32 * STG_LD);
+  constexpr int EMODE = MODE < 0 ? 0 : MODE;
+  // per-lane column constants, loaded once per tile
+  float bias0[4] = {0.f, 0.f, 0.f, 0.f}, bias1[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f};
+  int64_t ncol;  // first of this lane's 4 output columns (GLU: the linear column f)
+  if (MODE == EPI_GLU) {
+    const int cv = lane & 7;
+    ncol = ((n0 + wn * 64) >> 6) * 32 + 4 * cv;
+    if (e.bias && n0 + wn * 64 + 4 * cv < N) {
+      Vec4<bf16> bl, bg;
+      bl.load((const bf16*)e.bias + ncol);
+      bg.load((const bf16*)e.bias + (N >> 1) + ncol);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { bias0[j] = bl.v[j]; bias1[j] = bg.v[j]; }
+    }
+  } else {
+    ncol = n0 + wn * 64 + 4 * (lane & 15);
+    if (MODE != MODE_PARTIAL && ncol < N) {
+      if (e.bias) {
+        Vec4<bf16> b; b.load((const bf16*)e.bias + ncol);
+#pragma unroll
+        for (int j = 0; j < 4; j++) bias0[j] = b.v[j];
+      }
+      if (MODE == VITK_EPI_RESIDUAL && e.gamma) {
+        Vec4<TO> g; g.load((const TO*)e.gamma + ncol);
+#pragma unroll
+        for (int j = 0; j < 4; j++) gam[j] = g.v[j];
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; i++) {
 #pragma unroll
@@ -397,7 +487,6 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
     const int64_t mbase = m0 + wm * 64 + i * 32;
     if (MODE == EPI_GLU) {
       const int cv = lane & 7, rr = lane >> 3;
-      const int64_t f = ((n0 + wn * 64) >> 6) * 32 + 4 * cv;
 #pragma unroll
       for (int it = 0; it < 4; it++) {
         const int row = it * 8 + rr;
@@ -405,20 +494,30 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
         float lin[4], glu[4];
         *(float4*)lin = *(const float4*)(stg + row * STG_LD + 4 * cv);
         *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 4 * cv);
-        if (m < M && n0 + wn * 64 + 4 * cv < N) epi_glu<TO>(e, m, f, lin, glu);
+        if (m < M && n0 + wn * 64 + 4 * cv < N) epi_glu<TO>(e, m, ncol, lin, glu, bias0, bias1);
       }
     } else {
       const int cv = lane & 15, rr = lane >> 4;
-      const int64_t n = n0 + wn * 64 + 4 * cv;
 #pragma unroll
-      for (int it = 0; it < 8; it++) {
-        const int row = it * 4 + rr;
-        const int64_t m = mbase + row;
-        float v[4];
-        *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
-        if (m < M && n < N) {
-          if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + n) = *(const float4*)v;
-          else EpiVec<(MODE < 0 ? 0 : MODE), TO>::apply(e, m, n, v);
+      for (int half = 0; half < 2; half++) {   // 4 rows per lane at a time: fetch their memory operands, then finish them
+        EpiPre<EMODE, TO> pre[4];
+        if (MODE != MODE_PARTIAL) {
+#pragma unroll
+          for (int it = 0; it < 4; it++) {
+            const int64_t m = mbase + (half * 4 + it) * 4 + rr;
+            if (m < M && ncol < N) EpiVec<EMODE, TO>::prefetch(e, m, ncol, pre[it]);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+          const int row = (half * 4 + it) * 4 + rr;
+          const int64_t m = mbase + row;
+          float v[4];
+          *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
+          if (m < M && ncol < N) {
+            if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + ncol) = *(const float4*)v;
+            else EpiVec<EMODE, TO>::apply(e, m, ncol, v, bias0, gam, pre[it]);
+          }
         }
       }
     }
@@ -456,6 +555,12 @@ static bool mfma_ok(const VitkGemm* g) {
       !aligned16(g->pos))
     return false;
   if (!aligned16(g->a) || !aligned16(g->b)) return false;
+  // buffer-load offsets are 32-bit: a contraction-major operand is addressed from its first K row
+  const int64_t lim = 0xfffffff0ll;
+  if (g->trans_a && g->K * g->lda * 2 >= lim) return false;
+  if (g->trans_b && g->K * g->ldb * 2 >= lim) return false;
+  if (!g->trans_b && g->N * g->ldb * 2 >= lim) return false;
+  if (!g->trans_a && 128 * g->lda * 2 >= lim) return false;
   if (g->lda % 8 || g->ldb % 8) return false;
   if (!g->trans_a && g->K % 8) return false;
   if (g->trans_a && g->M % 8) return false;
@@ -468,9 +573,9 @@ static bool mfma_ok(const VitkGemm* g) {
 static int pick_splits(const VitkGemm* g) {
   if (g->epilogue != VITK_EPI_STORE) return 1;
   const int64_t tiles = ceil_div(g->M, BM) * ceil_div(g->N, BN);
-  if (tiles >= 256 || g->K < 1024) return 1;
-  int64_t s = ceil_div(768, tiles);
-  const int64_t smax = g->K / 512;
+  if (tiles >= 768 || g->K < 2048) return 1;   // 256 CUs x 3 resident blocks
+  int64_t s = ceil_div(1024, tiles);
+  const int64_t smax = g->K / 1024;
   if (s > smax) s = smax;
   if (s > 32) s = 32;
   return (int)(s < 1 ? 1 : s);

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_k(AttnP p) {
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int64_t qrow = (int64_t)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
   const bool qv = qrow < p.S;
+  const bool wave_on = (int64_t)blockIdx.x * (NW * 32) + wid * 32 < p.S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -379,15 +380,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_k(AttnP p) {
       stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, k0 + 64, p.S, Dh, tid);
       stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, k0 + 64, p.S, Dh, tid);
     }
+    if (!wave_on) continue;                    // this wave's 32 queries are all beyond S: only helps staging
+    const bool two = k0 + 32 < p.S;            // second 32-key half of the tile holds valid keys (wave-uniform)
     // scores: sacc[st][r] = S^T[key = k0 + st*32 + acc_row(r)][query = lane&31]
     f32x16 sacc[2];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) sacc[st][r] = 0.f;
+      for (int r = 0; r < 16; r++) sacc[st][r] = st == 0 ? 0.f : (two ? 0.f : -INFINITY);
+      if (st == 0 || two) {
 #pragma unroll
-      for (int ks = 0; ks < DHP / 16; ks++)
-        sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KS>(sK, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
+        for (int ks = 0; ks < DHP / 16; ks++)
+          sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KS>(sK, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
+      }
     }
     float mx = m;
 #pragma unroll
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_k(AttnP p) {
     for (int st = 0; st < 2; st++)
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
+        if (st == 1 && !two) continue;
         const bf16x8 pf = acc_to_frag(sacc[st], s2);
 #pragma unroll
         for (int dt = 0; dt < DHP / 32; dt++)
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int64_t qrow = (int64_t)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
   const bool qv = qrow < p.S;
+  const bool wave_on = (int64_t)blockIdx.x * (NW * 32) + wid * 32 < p.S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -489,8 +496,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
       stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, k0 + 64, p.S, Dh, tid);
       stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, k0 + 64, p.S, Dh, tid);
     }
+    if (!wave_on) continue;
 #pragma unroll
     for (int st = 0; st < 2; st++) {
+      if (st == 1 && k0 + 32 >= p.S) continue;   // no valid key in the second half of the last tile
       f32x16 sacc, pacc;
 #pragma unroll
       for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
@@ -533,6 +542,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int64_t krow = (int64_t)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
   const bool kvalid = krow < p.S;
+  const bool wave_on = (int64_t)blockIdx.x * (NW * 32) + wid * 32 < p.S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -572,8 +582,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
         rl = qq < p.S ? (tid < 64 ? p.lse[sbase + qq] * LOG2E : p.delta[sbase + qq]) : (tid < 64 ? INFINITY : 0.f);
       }
     }
+    if (!wave_on) continue;
 #pragma unroll
     for (int st = 0; st < 2; st++) {
+      if (st == 1 && q0 + 32 >= p.S) continue;   // no valid query in the second half of the last tile
       // sacc[r] = S[q = q0 + st*32 + acc_row(r)][key = lane&31], pacc likewise for dP
       f32x16 sacc, pacc;
 #pragma unroll

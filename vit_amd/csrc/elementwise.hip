@@ -394,11 +394,11 @@ extern "C" int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_
       void* dst = which == 0 ? dw : db;
       if (!dst) continue;
       if (w_dtype == VITK_F32)
-        hipLaunchKernelGGL((colsum_k<float, float, float>), g2, dim3(256), 0, st, ws + (size_t)which * D, 2 * D, nullptr,
-                           (const float*)nullptr, 0, (float*)dst, D, (int64_t)grid, D, 1.f);
+        colsum_one<float, float, float>(true, g2, st, ws + (size_t)which * D, 2 * D, nullptr, (const float*)nullptr, 0,
+                                        (float*)dst, D, (int64_t)grid, D, 1.f);
       else
-        hipLaunchKernelGGL((colsum_k<float, float, bf16>), g2, dim3(256), 0, st, ws + (size_t)which * D, 2 * D, nullptr,
-                           (const float*)nullptr, 0, (bf16*)dst, D, (int64_t)grid, D, 1.f);
+        colsum_one<float, float, bf16>(true, g2, st, ws + (size_t)which * D, 2 * D, nullptr, (const float*)nullptr, 0,
+                                       (bf16*)dst, D, (int64_t)grid, D, 1.f);
     }
     VITK_LAUNCH_CHECK("norm_bwd reduce");
   }

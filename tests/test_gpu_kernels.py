@@ -30,7 +30,7 @@ def test_library_loads_and_reports_errors():
 
 # ---------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 72), (384, 264, 200), (1000, 72, 328)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 72), (384, 264, 200), (1000, 72, 328), (768, 512, 448)])
 def test_mfma_gemm_exact_on_integers(layout, shape):
     """A = small integers, B = asymmetric small integers: every product and sum is exact in bf16/fp32, so the
     MFMA kernel (operand lane maps, transposed LDS reads, C layout, tails) must match torch bit for bit."""
@@ -44,9 +44,10 @@ def test_mfma_gemm_exact_on_integers(layout, shape):
     out = torch.empty(M, N, device=DEV, dtype=torch.float32)
     K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out, algo=2)
     assert torch.equal(out, ref), f"max err {(out - ref).abs().max().item()}"
-    out1 = torch.empty_like(out)
-    K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out1, algo=1)
-    assert torch.equal(out1, ref)
+    for algo in (1, 3, 4):  # portable, 256x256-tile MFMA, 128x128-tile MFMA
+        out1 = torch.empty_like(out)
+        K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out1, algo=algo)
+        assert torch.equal(out1, ref), f"algo {algo}: max err {(out1 - ref).abs().max().item()}"
 
 
 def test_mfma_gemm_splitk_wgrad_shape():

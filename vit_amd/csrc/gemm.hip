@@ -291,16 +291,16 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 // fragment of the MFMA A operand (rows = M index) or B operand (cols = N index): 8 contraction values
 // k = ks*16 + 8*(lane>>5) + j for index r0 + (lane & 31).
-template <bool TR>
+template <bool TR, int TROW = TROW_B>
 __device__ __forceinline__ bf16x8 read_frag(const char* s, int r0, int ks, int lane) {
   if (!TR) {
     return *(const bf16x8*)(s + (r0 + (lane & 31)) * ROW_B + (ks * 16 + 8 * (lane >> 5)) * 2);
   } else {
     const int kbase = ks * 16 + 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int col = r0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const char* p = s + kbase * TROW_B + col * 2;
+    const char* p = s + kbase * TROW + col * 2;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * TROW_B));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * TROW));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -331,18 +331,18 @@ struct TileSrc {
 
 __device__ __forceinline__ uint32_t clip32(int64_t v) { return v > 0xfffffff0ll ? 0xfffffff0u : (uint32_t)v; }
 
-template <bool TR, bool GLUMAP>
+template <bool TR, bool GLUMAP, int ROWS = 128, int NT = 256>
 __device__ __forceinline__ TileSrc make_src(const bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t nrows,
                                             int64_t kbeg, int64_t kend, int64_t Ktot, int tid) {
   TileSrc t;
   if (!TR) {
     const int64_t base_row = GLUMAP ? 0 : row0;
-    const int64_t span_rows = GLUMAP ? nrows : (nrows - row0 < 128 ? nrows - row0 : 128);
+    const int64_t span_rows = GLUMAP ? nrows : (nrows - row0 < ROWS ? nrows - row0 : ROWS);
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + base_row * ld), 0, clip32(((span_rows - 1) * ld + Ktot) * 2), 0x00020000);
     t.kstride = 2;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int c = tid + i * 256;
+      const int c = tid + i * NT;
       const int64_t r = row0 + (c >> 3);
       const int64_t rr = GLUMAP ? glu_row(r, nrows >> 1) : (int64_t)(c >> 3);
       t.voff[i] = r < nrows ? (uint32_t)((rr * ld + kbeg + (c & 7) * 8) * 2) : OOB;
@@ -354,9 +354,10 @@ __device__ __forceinline__ TileSrc make_src(const bf16* __restrict__ g, int64_t 
     t.kstride = (uint32_t)(ld * 2);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int c = tid + i * 256;
-      const int64_t col = row0 + (c & 15) * 8;
-      t.voff[i] = col < nrows ? (uint32_t)(((int64_t)(c >> 4) * ld + (c & 15) * 8) * 2) : OOB;
+      const int c = tid + i * NT;
+      constexpr int CPR = ROWS / 8;  // 16-byte chunks per k-row
+      const int64_t col = row0 + (c % CPR) * 8;
+      t.voff[i] = col < nrows ? (uint32_t)(((int64_t)(c / CPR) * ld + (c % CPR) * 8) * 2) : OOB;
       t.klim[i] = 0x7fffffff;
     }
   }
@@ -375,14 +376,110 @@ __device__ __forceinline__ void load_tile(uint4 (&r)[4], const TileSrc& t, int32
   }
 }
 
-template <bool TR>
+template <bool TR, int ROWS = 128, int NT = 256>
 __device__ __forceinline__ void store_tile(const uint4 (&r)[4], char* s, int tid) {
+  constexpr int CPR = ROWS / 8, TROW = ROWS * 2 + 64;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int c = tid + i * 256;
+    const int c = tid + i * NT;
     if (!TR) *(uint4*)(s + (c >> 3) * ROW_B + (c & 7) * 16) = r[i];
-    else *(uint4*)(s + (c >> 4) * TROW_B + (c & 15) * 16) = r[i];
+    else *(uint4*)(s + (c / CPR) * TROW + (c % CPR) * 16) = r[i];
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the MFMA kernels.  Accumulator element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column
+// l&31 of a 32x32 tile; a wave transposes 32 rows x 64 columns at a time through its own LDS slab (row stride 68
+// floats) so that every lane then owns 4 consecutive columns: 16-byte loads of bias/residual, 8/16-byte stores,
+// whole 128-B lines per row.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, class TO>
+struct EpiCols {  // per-lane column constants, loaded once per tile
+  float bias0[4], bias1[4], gam[4];
+  int64_t ncol;   // first of this lane's 4 output columns (GLU: the linear column f)
+  __device__ __forceinline__ void init(const Epi& e, int64_t nwave, int64_t N, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { bias0[j] = 0.f; bias1[j] = 0.f; gam[j] = 1.f; }
+    if (MODE == EPI_GLU) {
+      const int cv = lane & 7;
+      ncol = (nwave >> 6) * 32 + 4 * cv;
+      if (e.bias && nwave + 4 * cv < N) {
+        Vec4<bf16> bl, bg;
+        bl.load((const bf16*)e.bias + ncol);
+        bg.load((const bf16*)e.bias + (N >> 1) + ncol);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { bias0[j] = bl.v[j]; bias1[j] = bg.v[j]; }
+      }
+    } else {
+      ncol = nwave + 4 * (lane & 15);
+      if (MODE != MODE_PARTIAL && ncol < N) {
+        if (e.bias) {
+          Vec4<bf16> b; b.load((const bf16*)e.bias + ncol);
+#pragma unroll
+          for (int j = 0; j < 4; j++) bias0[j] = b.v[j];
+        }
+        if (MODE == VITK_EPI_RESIDUAL && e.gamma) {
+          Vec4<TO> g; g.load((const TO*)e.gamma + ncol);
+#pragma unroll
+          for (int j = 0; j < 4; j++) gam[j] = g.v[j];
+        }
+      }
+    }
+  }
+};
+
+// one 32-row x 64-column slab of a wave's tile: a0 = columns 0..31, a1 = columns 32..63.  All waves of the block call
+// this the same number of times (it contains block barriers).
+template <int MODE, class TO, int PF = 4>
+__device__ __forceinline__ void epilogue_slab(const Epi& e, const EpiCols<MODE, TO>& cols, float* stg, const f32x16& a0,
+                                              const f32x16& a1, int64_t mbase, int64_t nwave, int64_t M, int64_t N,
+                                              int64_t split, float* __restrict__ partial, int lane) {
+  constexpr int EMODE = MODE < 0 ? 0 : MODE;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    stg[row * STG_LD + (lane & 31)] = a0[r];
+    stg[row * STG_LD + 32 + (lane & 31)] = a1[r];
+  }
+  __syncthreads();
+  const int64_t ncol = cols.ncol;
+  if (MODE == EPI_GLU) {
+    const int cv = lane & 7, rr = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + rr;
+      const int64_t m = mbase + row;
+      float lin[4], glu[4];
+      *(float4*)lin = *(const float4*)(stg + row * STG_LD + 4 * cv);
+      *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 4 * cv);
+      if (m < M && nwave + 4 * cv < N) epi_glu<TO>(e, m, ncol, lin, glu, cols.bias0, cols.bias1);
+    }
+  } else {
+    const int cv = lane & 15, rr = lane >> 4;
+#pragma unroll
+    for (int half = 0; half < 8 / PF; half++) {   // PF rows per lane at a time: fetch their memory operands, then finish them
+      EpiPre<EMODE, TO> pre[PF];
+      if (MODE != MODE_PARTIAL) {
+#pragma unroll
+        for (int it = 0; it < PF; it++) {
+          const int64_t m = mbase + (half * PF + it) * 4 + rr;
+          if (m < M && ncol < N) EpiVec<EMODE, TO>::prefetch(e, m, ncol, pre[it]);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < PF; it++) {
+        const int row = (half * PF + it) * 4 + rr;
+        const int64_t m = mbase + row;
+        float v[4];
+        *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
+        if (m < M && ncol < N) {
+          if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + ncol) = *(const float4*)v;
+          else EpiVec<EMODE, TO>::apply(e, m, ncol, v, cols.bias0, cols.gam, pre[it]);
+        }
+      }
+    }
+  }
+  __syncthreads();
 }
 
 // blocks that share an XCD (bid % 8) get consecutive tile ids, so one L2 sees neighbouring tiles
@@ -443,86 +540,134 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
     __syncthreads();
   }
 
-  // Epilogue.  Accumulator element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of a 32x32 tile; each
-  // wave transposes 32 rows x 64 columns at a time through its own LDS slab (row stride 68 floats) so that every
-  // lane then owns 4 consecutive columns: 16-byte loads of bias/residual and 8/16-byte stores, whole 128-B lines per row.
+  EpiCols<MODE, TO> cols;
+  cols.init(e, n0 + wn * 64, N, lane);
   float* stg = (float*)smem + wid * (32 * STG_LD);
-  constexpr int EMODE = MODE < 0 ? 0 : MODE;
-  // per-lane column constants, loaded once per tile
-  float bias0[4] = {0.f, 0.f, 0.f, 0.f}, bias1[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f};
-  int64_t ncol;  // first of this lane's 4 output columns (GLU: the linear column f)
-  if (MODE == EPI_GLU) {
-    const int cv = lane & 7;
-    ncol = ((n0 + wn * 64) >> 6) * 32 + 4 * cv;
-    if (e.bias && n0 + wn * 64 + 4 * cv < N) {
-      Vec4<bf16> bl, bg;
-      bl.load((const bf16*)e.bias + ncol);
-      bg.load((const bf16*)e.bias + (N >> 1) + ncol);
 #pragma unroll
-      for (int j = 0; j < 4; j++) { bias0[j] = bl.v[j]; bias1[j] = bg.v[j]; }
-    }
-  } else {
-    ncol = n0 + wn * 64 + 4 * (lane & 15);
-    if (MODE != MODE_PARTIAL && ncol < N) {
-      if (e.bias) {
-        Vec4<bf16> b; b.load((const bf16*)e.bias + ncol);
+  for (int i = 0; i < 2; i++)
+    epilogue_slab<MODE, TO>(e, cols, stg, acc[i][0], acc[i][1], m0 + wm * 64 + i * 32, n0 + wn * 64, M, N, split, partial, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x256x64 kernel: 8 waves (2 x 4), each a 128x64 tile (4 x 2 MFMA tiles, 128 accumulator registers), one
+// block per CU, LDS double-buffered (2 x 72 KiB).  A 128^2 tile re-reads its operands from L2 twice as often per
+// FLOP and spends as many LDS cycles staging and reading fragments as the MFMAs take; here every staged byte feeds
+// twice the MFMAs, and the two waves that share a SIMD are kept in opposite phases: each K-step is four barrier
+// intervals  R0 | M1 | R2 | M3  (R = LDS fragment reads for half a K-step + stage one operand of the next tile,
+// M = 16 MFMAs), and waves 4-7 run one interval behind waves 0-3, so while one wave of a SIMD multiplies, the other
+// reads.  Hazards are covered by the barriers alone: a buffer is refilled (intervals 4k..4k+3) only after its last
+// read (interval 4k-1) and read again from interval 4k+4.
+// ------------------------------------------------------------------------------------------------
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int TROW2_B = BM2 * 2 + 64;   // 576 B: contraction-major tile [64][256] bf16, rows padded by 64 B
+constexpr int TILE2_B = 36864;          // 256*144 == 64*576
+
+__device__ __forceinline__ void phase_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool TA, bool TB, int MODE, class TO>
+__global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A, const bf16* __restrict__ B, int64_t M,
+                                                      int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
+                                                      int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE2_B];   // [buffer][A|B]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int grp = wid >> 2;            // waves w and w+4 share a SIMD; grp 1 runs one interval behind grp 0
+  const int wm = grp, wn = wid & 3;    // wave tile: rows [wm*128, +128), columns [wn*64, +64)
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  const int64_t m0 = tm * BM2, n0 = tn * BN2;
+  const int64_t kbeg = split * klen;
+  const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
+  const int32_t klen_here = (int32_t)(kend - kbeg);
+  const int nk = (klen_here + BK - 1) / BK;
+
+  f32x16 acc[4][2];
 #pragma unroll
-        for (int j = 0; j < 4; j++) bias0[j] = b.v[j];
-      }
-      if (MODE == VITK_EPI_RESIDUAL && e.gamma) {
-        Vec4<TO> g; g.load((const TO*)e.gamma + ncol);
-#pragma unroll
-        for (int j = 0; j < 4; j++) gam[j] = g.v[j];
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++)
-        stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-    __syncthreads();
-    const int64_t mbase = m0 + wm * 64 + i * 32;
-    if (MODE == EPI_GLU) {
-      const int cv = lane & 7, rr = lane >> 3;
-#pragma unroll
-      for (int it = 0; it < 4; it++) {
-        const int row = it * 8 + rr;
-        const int64_t m = mbase + row;
-        float lin[4], glu[4];
-        *(float4*)lin = *(const float4*)(stg + row * STG_LD + 4 * cv);
-        *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 4 * cv);
-        if (m < M && n0 + wn * 64 + 4 * cv < N) epi_glu<TO>(e, m, ncol, lin, glu, bias0, bias1);
-      }
-    } else {
-      const int cv = lane & 15, rr = lane >> 4;
-#pragma unroll
-      for (int half = 0; half < 2; half++) {   // 4 rows per lane at a time: fetch their memory operands, then finish them
-        EpiPre<EMODE, TO> pre[4];
-        if (MODE != MODE_PARTIAL) {
-#pragma unroll
-          for (int it = 0; it < 4; it++) {
-            const int64_t m = mbase + (half * 4 + it) * 4 + rr;
-            if (m < M && ncol < N) EpiVec<EMODE, TO>::prefetch(e, m, ncol, pre[it]);
-          }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-          const int row = (half * 4 + it) * 4 + rr;
-          const int64_t m = mbase + row;
-          float v[4];
-          *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
-          if (m < M && ncol < N) {
-            if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + ncol) = *(const float4*)v;
-            else EpiVec<EMODE, TO>::apply(e, m, ncol, v, bias0, gam, pre[it]);
-          }
-        }
-      }
-    }
-    __syncthreads();
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const TileSrc srcA = make_src<TA, false, 256, 512>(A, lda, m0, M, kbeg, kend, K, tid);
+  const TileSrc srcB = make_src<TB, MODE == EPI_GLU, 256, 512>(B, ldb, n0, N, kbeg, kend, K, tid);
+  uint4 ra[4], rb[4];
+  load_tile<TA>(ra, srcA, 0);
+  load_tile<TB>(rb, srcB, 0);
+  store_tile<TA, 256, 512>(ra, smem, tid);
+  store_tile<TB, 256, 512>(rb, smem + TILE2_B, tid);
+  if (nk > 1) {
+    load_tile<TA>(ra, srcA, BK);
+    load_tile<TB>(rb, srcB, BK);
   }
+  phase_barrier();
+  if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+  for (int k = 0; k < nk; k++) {
+    const char* cA = smem + (k & 1) * 2 * TILE2_B;
+    const char* cB = cA + TILE2_B;
+    char* nA = smem + ((k + 1) & 1) * 2 * TILE2_B;
+    char* nB = nA + TILE2_B;
+    bf16x8 af[2][4], bfr[2][2];
+    // ---- R0: fragments of k-substeps 0,1; stage A of tile k+1; fetch A of tile k+2
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[ks][i] = read_frag<TA, TROW2_B>(cA, wm * 128 + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; j++) bfr[ks][j] = read_frag<TB, TROW2_B>(cB, wn * 64 + j * 32, ks, lane);
+    }
+    if (k + 1 < nk) {
+      store_tile<TA, 256, 512>(ra, nA, tid);
+      if (k + 2 < nk) load_tile<TA>(ra, srcA, (k + 2) * BK);
+    }
+    phase_barrier();
+    // ---- M1
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    phase_barrier();
+    // ---- R2: fragments of k-substeps 2,3; stage B of tile k+1; fetch B of tile k+2
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[ks][i] = read_frag<TA, TROW2_B>(cA, wm * 128 + i * 32, ks + 2, lane);
+#pragma unroll
+      for (int j = 0; j < 2; j++) bfr[ks][j] = read_frag<TB, TROW2_B>(cB, wn * 64 + j * 32, ks + 2, lane);
+    }
+    if (k + 1 < nk) {
+      store_tile<TB, 256, 512>(rb, nB, tid);
+      if (k + 2 < nk) load_tile<TB>(rb, srcB, (k + 2) * BK);
+    }
+    phase_barrier();
+    // ---- M3
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    phase_barrier();
+  }
+  if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  __syncthreads();
+
+  EpiCols<MODE, TO> cols;
+  cols.init(e, n0 + wn * 64, N, lane);
+  float* stg = (float*)smem + wid * (32 * STG_LD);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    epilogue_slab<MODE, TO, 2>(e, cols, stg, acc[i][0], acc[i][1], m0 + wm * 128 + i * 32, n0 + wn * 64, M, N, split, partial, lane);
 }
 
 template <int MODE, class TI, class TO>
@@ -570,14 +715,17 @@ static bool mfma_ok(const VitkGemm* g) {
 }
 
 // split the contraction when the output has too few tiles to fill 256 CUs (weight gradients)
+static bool use_tile256(const VitkGemm* g);
 static int pick_splits(const VitkGemm* g) {
   if (g->epilogue != VITK_EPI_STORE) return 1;
-  const int64_t tiles = ceil_div(g->M, BM) * ceil_div(g->N, BN);
-  if (tiles >= 768 || g->K < 2048) return 1;   // 256 CUs x 3 resident blocks
-  int64_t s = ceil_div(1024, tiles);
+  const bool big = use_tile256(g);
+  const int64_t tiles = big ? ceil_div(g->M, BM2) * ceil_div(g->N, BN2) : ceil_div(g->M, BM) * ceil_div(g->N, BN);
+  const int64_t want = big ? 512 : 1024;       // blocks that fill 256 CUs twice (one 256^2 block or three 128^2 per CU)
+  if (tiles >= (big ? 256 : 768) || g->K < 2048) return 1;
+  int64_t s = want / tiles;
   const int64_t smax = g->K / 1024;
   if (s > smax) s = smax;
-  if (s > 32) s = 32;
+  if (s > 64) s = 64;
   return (int)(s < 1 ? 1 : s);
 }
 
@@ -612,8 +760,24 @@ static void launch_simple(const VitkGemm* g, const Epi& e, hipStream_t st) {
 #undef LS
 }
 
+// algo 3 forces the 256^2 kernel, algo 4 the 128^2 kernel; otherwise large problems take the 256^2 tile
+static bool use_tile256(const VitkGemm* g) {
+  if (g->algo == 3) return true;
+  if (g->algo == 4) return false;
+  if (g->epilogue == VITK_EPI_DGLU) return false;   // its epilogue does not fit the register budget beside 128 accumulators
+  // measured on MI355X (ViT-B shapes): the 256^2 tile wins once the output is wide or the contraction long;
+  // narrow, short problems (N = K = 768) keep more CUs busy with 128^2 tiles
+  return g->M >= 512 && g->N >= 512 && (g->N >= 1024 || g->K >= 2048);
+}
+
 template <bool TA, bool TB, int MODE, class TO>
 static void launch_mfma_one(const VitkGemm* g, const Epi& e, int splits, int64_t klen, float* partial, hipStream_t st) {
+  if (use_tile256(g)) {
+    const int64_t tm = ceil_div(g->M, BM2), tn = ceil_div(g->N, BN2);
+    hipLaunchKernelGGL((gemm_mfma256_k<TA, TB, MODE, TO>), dim3((unsigned)(tm * tn * splits)), dim3(512), 0, st,
+                       (const bf16*)g->a, (const bf16*)g->b, g->M, g->N, g->K, g->lda, g->ldb, tm, tn, klen, e, partial);
+    return;
+  }
   const int64_t tm = ceil_div(g->M, BM), tn = ceil_div(g->N, BN);
   dim3 grid((unsigned)(tm * tn * splits)), block(256);
   hipLaunchKernelGGL((gemm_mfma_k<TA, TB, MODE, TO>), grid, block, 0, st, (const bf16*)g->a, (const bf16*)g->b, g->M, g->N,
@@ -675,7 +839,7 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const Epi e = make_epi(g);
   const bool can = mfma_ok(g);
-  VITK_REQUIRE(g->algo != 2 || can, "gemm: MFMA kernel cannot take this problem (dtype/alignment/layout)");
+  VITK_REQUIRE(g->algo < 2 || can, "gemm: MFMA kernel cannot take this problem (dtype/alignment/layout)");
   VITK_REQUIRE(!fusedact || (can && g->algo != 1), "gemm: fused activation epilogues exist in the MFMA kernel only");
   if (can && g->algo != 1) {
     if (g->out_dtype == VITK_F32) launch_mfma<float>(g, e, st);

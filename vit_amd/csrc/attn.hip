@@ -15,6 +15,7 @@
 // [B,S,3,H,Dh] and write [B,S,H*Dh] directly (no head split / merge copies).
 // Portable kernels (any dtype, Dh <= 128, fp32 math) implement the same three passes with scalar code.
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnP {
   const void *q, *k, *v, *dout;
@@ -341,88 +342,99 @@ __device__ __forceinline__ void store_rows(bf16* __restrict__ dst, const f32x16 
     }
 }
 
-template <int DHP, int NW>
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // one v_exp_f32
+
+#define ZERO16 {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
+
+template <int DHP, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int KS = Strides<DHP>::ROWS, VS = Strides<DHP>::COLS;
   __shared__ __attribute__((aligned(16))) char smem[64 * KS + 64 * VS];
   char* sK = smem;
   char* sV = smem + 64 * KS;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh, S = (int)p.S;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int64_t qrow = (int64_t)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
-  const bool qv = qrow < p.S;
-  const bool wave_on = (int64_t)blockIdx.x * (NW * 32) + wid * 32 < p.S;
+  const int qrow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
+  const bool qv = qrow < S;
+  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
 
   bf16x8 qf[DHP / 16];
   load_stationary<DHP>(qf, qp, p.q_ss, qrow, qv, Dh, lane);
+  const f32x16 zero = ZERO16;
   f32x16 oacc[DHP / 32];
 #pragma unroll
-  for (int dt = 0; dt < DHP / 32; dt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) oacc[dt][r] = 0.f;
+  for (int dt = 0; dt < DHP / 32; dt++) oacc[dt] = zero;
   float m = -INFINITY, l = 0.f;
   const float c = p.scale * LOG2E;
   const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.S;
+  const int rowoff = 4 * (lane >> 5);   // accumulator register r holds key row (r&3) + 8*(r>>2) + rowoff
 
   uint4 rk[NCH], rv[NCH];
   stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, 0, p.S, Dh, tid);
   stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, 0, p.S, Dh, tid);
-  for (int64_t k0 = 0; k0 < p.S; k0 += 64) {
+  for (int k0 = 0; k0 < S; k0 += 64) {
     __syncthreads();
     stage_store<DHP, NT, NCH, KS>(rk, sK, tid);
     stage_store<DHP, NT, NCH, VS>(rv, sV, tid);
     __syncthreads();
-    if (k0 + 64 < p.S) {
+    if (k0 + 64 < S) {
       stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, k0 + 64, p.S, Dh, tid);
       stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, k0 + 64, p.S, Dh, tid);
     }
-    if (!wave_on) continue;                    // this wave's 32 queries are all beyond S: only helps staging
-    const bool two = k0 + 32 < p.S;            // second 32-key half of the tile holds valid keys (wave-uniform)
-    // scores: sacc[st][r] = S^T[key = k0 + st*32 + acc_row(r)][query = lane&31]
+    if (!wave_on) continue;                    // this wave's 32 queries are all beyond S: it only helps staging
+    const bool two = k0 + 32 < S;              // the second 32-key half of the tile holds valid keys (wave-uniform)
+    // scores: sacc[st][r] = S^T[key = k0 + st*32 + row(r)][query = lane&31]
     f32x16 sacc[2];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) sacc[st][r] = st == 0 ? 0.f : (two ? 0.f : -INFINITY);
+      sacc[st] = zero;
       if (st == 0 || two) {
 #pragma unroll
         for (int ks = 0; ks < DHP / 16; ks++)
           sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KS>(sK, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
       }
     }
+    if (k0 + 64 > S) {                         // last, partial tile: keys beyond S get probability 0
+#pragma unroll
+      for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (k0 + st * 32 + (r & 3) + 8 * (r >> 2) + rowoff >= S) sacc[st][r] = -INFINITY;
+    }
     float mx = m;
 #pragma unroll
     for (int st = 0; st < 2; st++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        if (k0 + st * 32 + acc_row(r, lane) >= p.S) sacc[st][r] = -INFINITY;
-        mx = fmaxf(mx, sacc[st][r]);
-      }
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[st][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float alpha = exp2f((m - mx) * c);
-    m = mx;
+    const float nmc = -mx * c;
     float psum = 0.f;
 #pragma unroll
     for (int st = 0; st < 2; st++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        float pr = exp2f((sacc[st][r] - mx) * c);
+        float pr = fast_exp2(fmaf(sacc[st][r], c, nmc));
         psum += pr;
-        if (p.thr) {
-          const uint64_t key = (uint64_t)(k0 + st * 32 + acc_row(r, lane));
+        if (DROP) {
+          const uint64_t key = (uint64_t)(k0 + st * 32 + (r & 3) + 8 * (r >> 2) + rowoff);
           pr = rng_u32(p.seed, rbase + key) >= p.thr ? pr * p.keep_scale : 0.f;
         }
         sacc[st][r] = pr;
       }
-    l = l * alpha + psum;
+    if (__any(mx != m)) {                      // running max moved for some query of this wave: rescale O and l
+      const float alpha = fast_exp2((m - mx) * c);
+      l *= alpha;
 #pragma unroll
-    for (int dt = 0; dt < DHP / 32; dt++)
+      for (int dt = 0; dt < DHP / 32; dt++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+        for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+      m = mx;
+    }
+    l += psum;
     // O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
     for (int st = 0; st < 2; st++)
@@ -437,22 +449,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_k(AttnP p) {
   }
   l += __shfl_xor(l, 32, 64);
   if (!qv) return;
-  store_rows<DHP>((bf16*)p.o + b * p.o_sb + h * p.o_sh + qrow * p.o_ss, oacc, 1.f / l, Dh, lane);
+  store_rows<DHP>((bf16*)p.o + b * p.o_sb + h * p.o_sh + (int64_t)qrow * p.o_ss, oacc, 1.f / l, Dh, lane);
   if (lane < 32) p.lse[(b * p.H + h) * p.S + qrow] = m * p.scale + logf(l);
 }
 
-template <int DHP, int NW>
+template <int DHP, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int KS = Strides<DHP>::COLS, VS = Strides<DHP>::ROWS;  // K is read both ways, V row-wise only
   __shared__ __attribute__((aligned(16))) char smem[64 * KS + 64 * VS];
   char* sK = smem;
   char* sV = smem + 64 * KS;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh, S = (int)p.S;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int64_t qrow = (int64_t)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
-  const bool qv = qrow < p.S;
-  const bool wave_on = (int64_t)blockIdx.x * (NW * 32) + wid * 32 < p.S;
+  const int qrow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
+  const bool qv = qrow < S;
+  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   load_stationary<DHP>(qf, qp, p.q_ss, qrow, qv, Dh, lane);
   load_stationary<DHP>(gf, gp, p.o_ss, qrow, qv, Dh, lane);
   const int64_t srow = (b * p.H + h) * p.S + qrow;
-  const float lse2 = qv ? p.lse[srow] * LOG2E : 0.f;
+  const float nlse2 = qv ? -p.lse[srow] * LOG2E : 0.f;
   // delta = rowsum(dO * O), computed here (each half-wave holds half of the row) and published for attn_dkdv_k,
   // which is launched after this kernel on the same stream
   float delta = 0.f;
@@ -478,43 +490,43 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   }
   const float c = p.scale * LOG2E;
   const uint64_t rbase = (uint64_t)srow * p.S;
+  const int rowoff = 4 * (lane >> 5);
+  const f32x16 zero = ZERO16;
   f32x16 dqacc[DHP / 32];
 #pragma unroll
-  for (int dt = 0; dt < DHP / 32; dt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) dqacc[dt][r] = 0.f;
+  for (int dt = 0; dt < DHP / 32; dt++) dqacc[dt] = zero;
 
   uint4 rk[NCH], rv[NCH];
   stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, 0, p.S, Dh, tid);
   stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, 0, p.S, Dh, tid);
-  for (int64_t k0 = 0; k0 < p.S; k0 += 64) {
+  for (int k0 = 0; k0 < S; k0 += 64) {
     __syncthreads();
     stage_store<DHP, NT, NCH, KS>(rk, sK, tid);
     stage_store<DHP, NT, NCH, VS>(rv, sV, tid);
     __syncthreads();
-    if (k0 + 64 < p.S) {
+    if (k0 + 64 < S) {
       stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, k0 + 64, p.S, Dh, tid);
       stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, k0 + 64, p.S, Dh, tid);
     }
     if (!wave_on) continue;
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-      if (st == 1 && k0 + 32 >= p.S) continue;   // no valid key in the second half of the last tile
-      f32x16 sacc, pacc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
+      if (st == 1 && k0 + 32 >= S) continue;   // no valid key in the second half of the last tile
+      f32x16 sacc = zero, pacc = zero;
 #pragma unroll
       for (int ks = 0; ks < DHP / 16; ks++) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KS>(sK, st * 32, ks, lane), qf[ks], sacc, 0, 0, 0);
         pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<VS>(sV, st * 32, ks, lane), gf[ks], pacc, 0, 0, 0);
       }
       // dS^T[key][q] = P (dP - delta); keys beyond S contribute nothing
+      const bool partial = k0 + st * 32 + 32 > S;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int64_t key = k0 + st * 32 + acc_row(r, lane);
-        const float pr = key < p.S ? exp2f(sacc[r] * c - lse2) : 0.f;
+        const int key = k0 + st * 32 + (r & 3) + 8 * (r >> 2) + rowoff;
+        float pr = fast_exp2(fmaf(sacc[r], c, nlse2));
+        if (partial) pr = key < S ? pr : 0.f;
         float dp = pacc[r];
-        if (p.thr) dp = rng_u32(p.seed, rbase + (uint64_t)key) >= p.thr ? dp * p.keep_scale : 0.f;
+        if (DROP) dp = rng_u32(p.seed, rbase + (uint64_t)key) >= p.thr ? dp * p.keep_scale : 0.f;
         sacc[r] = pr * (dp - delta);
       }
 #pragma unroll
@@ -527,22 +539,22 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
     }
   }
   if (!qv) return;
-  store_rows<DHP>((bf16*)p.dq + b * p.g_sb + h * p.g_sh + qrow * p.g_ss, dqacc, p.scale, Dh, lane);
+  store_rows<DHP>((bf16*)p.dq + b * p.g_sb + h * p.g_sh + (int64_t)qrow * p.g_ss, dqacc, p.scale, Dh, lane);
 }
 
-template <int DHP, int NW>
+template <int DHP, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int QS = Strides<DHP>::COLS;  // Q and dO tiles are read both ways
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * QS + 512];
   char* sQ = smem;
   char* sG = smem + 64 * QS;
-  float* sL = (float*)(smem + 2 * 64 * QS);  // lse2[64], delta[64]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh;
+  float* sL = (float*)(smem + 2 * 64 * QS);  // -lse*log2e [64], delta[64]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh, S = (int)p.S;
   const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int64_t krow = (int64_t)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
-  const bool kvalid = krow < p.S;
-  const bool wave_on = (int64_t)blockIdx.x * (NW * 32) + wid * 32 < p.S;
+  const int krow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
+  const bool kvalid = krow < S;
+  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -553,43 +565,41 @@ __global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
   load_stationary<DHP>(vf, vp, p.q_ss, krow, kvalid, Dh, lane);
   const int64_t sbase = (b * p.H + h) * p.S;
   const float c = p.scale * LOG2E;
+  const int rowoff = 4 * (lane >> 5);
+  const f32x16 zero = ZERO16;
   f32x16 dkacc[DHP / 32], dvacc[DHP / 32];
 #pragma unroll
-  for (int dt = 0; dt < DHP / 32; dt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) { dkacc[dt][r] = 0.f; dvacc[dt][r] = 0.f; }
+  for (int dt = 0; dt < DHP / 32; dt++) { dkacc[dt] = zero; dvacc[dt] = zero; }
 
   uint4 rq[NCH], rg[NCH];
   float rl = 0.f;
+  // rows beyond S: -lse = -inf makes their probability exactly 0
+  auto load_row_consts = [&](int q0) {
+    if (tid < 128) {
+      const int qq = q0 + (tid & 63);
+      rl = qq < S ? (tid < 64 ? -p.lse[sbase + qq] * LOG2E : p.delta[sbase + qq]) : (tid < 64 ? -INFINITY : 0.f);
+    }
+  };
   stage_load<DHP, NT, NCH>(rq, qp, p.q_ss, 0, p.S, Dh, tid);
   stage_load<DHP, NT, NCH>(rg, gp, p.o_ss, 0, p.S, Dh, tid);
-  if (tid < 128) {
-    const int64_t qq = tid & 63;
-    // rows beyond S: lse = +inf makes their probability exactly 0
-    rl = qq < p.S ? (tid < 64 ? p.lse[sbase + qq] * LOG2E : p.delta[sbase + qq]) : (tid < 64 ? INFINITY : 0.f);
-  }
-  for (int64_t q0 = 0; q0 < p.S; q0 += 64) {
+  load_row_consts(0);
+  for (int q0 = 0; q0 < S; q0 += 64) {
     __syncthreads();
     stage_store<DHP, NT, NCH, QS>(rq, sQ, tid);
     stage_store<DHP, NT, NCH, QS>(rg, sG, tid);
     if (tid < 128) sL[tid] = rl;
     __syncthreads();
-    if (q0 + 64 < p.S) {
+    if (q0 + 64 < S) {
       stage_load<DHP, NT, NCH>(rq, qp, p.q_ss, q0 + 64, p.S, Dh, tid);
       stage_load<DHP, NT, NCH>(rg, gp, p.o_ss, q0 + 64, p.S, Dh, tid);
-      if (tid < 128) {
-        const int64_t qq = q0 + 64 + (tid & 63);
-        rl = qq < p.S ? (tid < 64 ? p.lse[sbase + qq] * LOG2E : p.delta[sbase + qq]) : (tid < 64 ? INFINITY : 0.f);
-      }
+      load_row_consts(q0 + 64);
     }
     if (!wave_on) continue;
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-      if (st == 1 && q0 + 32 >= p.S) continue;   // no valid query in the second half of the last tile
-      // sacc[r] = S[q = q0 + st*32 + acc_row(r)][key = lane&31], pacc likewise for dP
-      f32x16 sacc, pacc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) { sacc[r] = 0.f; pacc[r] = 0.f; }
+      if (st == 1 && q0 + 32 >= S) continue;   // no valid query in the second half of the last tile
+      // sacc[r] = S[q = q0 + st*32 + row(r)][key = lane&31], pacc likewise for dP
+      f32x16 sacc = zero, pacc = zero;
 #pragma unroll
       for (int ks = 0; ks < DHP / 16; ks++) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<QS>(sQ, st * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
@@ -597,15 +607,15 @@ __global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
       }
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const int ql = st * 32 + 8 * g + 4 * (lane >> 5);
+        const int ql = st * 32 + 8 * g + rowoff;
         const f32x4 l4 = *(const f32x4*)(sL + ql);
         const f32x4 d4 = *(const f32x4*)(sL + 64 + ql);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int r = 4 * g + j;
-          const float pr = exp2f(sacc[r] * c - l4[j]);
+          const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
           float pd = pr, dp = pacc[r];
-          if (p.thr) {
+          if (DROP) {
             const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.S + (uint64_t)krow) >= p.thr;
             pd = keep ? pr * p.keep_scale : 0.f;
             dp = keep ? dp * p.keep_scale : 0.f;
@@ -627,8 +637,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
     }
   }
   if (!kvalid) return;
-  store_rows<DHP>((bf16*)p.dk + b * p.g_sb + h * p.g_sh + krow * p.g_ss, dkacc, p.scale, Dh, lane);
-  store_rows<DHP>((bf16*)p.dv + b * p.g_sb + h * p.g_sh + krow * p.g_ss, dvacc, 1.f, Dh, lane);
+  store_rows<DHP>((bf16*)p.dk + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dkacc, p.scale, Dh, lane);
+  store_rows<DHP>((bf16*)p.dv + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dvacc, 1.f, Dh, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,12 +679,20 @@ static int attn_validate(const VitkAttn* a, bool bwd) {
   return 0;
 }
 // 4 waves (128 rows) per workgroup when that wastes little of the last block, else 2 waves (64 rows)
-static int pick_nw(int64_t S, int64_t Dh) { return (Dh > 96 || S % 128 == 0 || S % 128 > 64 || S >= 2048) ? 4 : 2; }
+static int pick_nw(int64_t S, int64_t Dh) {
+  if (const char* f = getenv("VITK_ATTN_NW")) return atoi(f) == 2 ? 2 : 4;
+  return (Dh > 96 || S % 128 == 0 || S % 128 > 64 || S >= 2048) ? 4 : 2;
+}
 
 #define ATTN_DISPATCH(KERNEL, DHP, NW, grid, p, st)                                             \
   do {                                                                                          \
-    if (NW == 4) hipLaunchKernelGGL((KERNEL<DHP, 4>), grid, dim3(256), 0, st, p);               \
-    else hipLaunchKernelGGL((KERNEL<DHP, 2>), grid, dim3(128), 0, st, p);                       \
+    if (p.thr) {                                                                                \
+      if (NW == 4) hipLaunchKernelGGL((KERNEL<DHP, 4, true>), grid, dim3(256), 0, st, p);       \
+      else hipLaunchKernelGGL((KERNEL<DHP, 2, true>), grid, dim3(128), 0, st, p);               \
+    } else {                                                                                    \
+      if (NW == 4) hipLaunchKernelGGL((KERNEL<DHP, 4, false>), grid, dim3(256), 0, st, p);      \
+      else hipLaunchKernelGGL((KERNEL<DHP, 2, false>), grid, dim3(128), 0, st, p);              \
+    }                                                                                           \
   } while (0)
 #define ATTN_DISPATCH_DH(KERNEL, Dh, NW, grid, p, st)                  \
   do {                                                                 \

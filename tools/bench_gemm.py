@@ -38,7 +38,10 @@ cases = [  # name, layout, M, N, K, epilogue, out dtype
     ("fc1 fwd", "nt", M, 2 * F, D, "store", torch.bfloat16),
     ("out fwd", "nt", M, D, D, "res", torch.float32),
     ("fc2 fwd", "nt", M, D, F, "res", torch.float32),
+    ("fc1 glu", "nt", M, 2 * F, D, "glu", torch.bfloat16),
     ("fc2 dgrad", "nn", M, F, D, "store", torch.bfloat16),
+    ("fc2 dglu", "nn", M, F, D, "dglu", torch.bfloat16),
+    ("fc2 dglu0", "nn", M, F, D, "dglu0", torch.bfloat16),   # relu gate: the same memory traffic, trivial arithmetic
     ("fc1 dgrad", "nn", M, D, 2 * F, "store", torch.bfloat16),
     ("qkv dgrad", "nn", M, D, 3 * D, "store", torch.bfloat16),
     ("out dgrad", "nn", M, D, D, "store", torch.bfloat16),
@@ -65,6 +68,12 @@ for name, layout, m, n, k, epi, odt in cases:
     if epi == "res":
         res = torch.randn(m, n, device=dev)
         kw = dict(epilogue=L.EPI_RESIDUAL, res=res, bias=rnd(n))
+    if epi == "glu":    # out = silu(gate) * value, pre-activations kept in aux
+        out = torch.empty(m, n // 2, device=dev, dtype=odt)
+        kw = dict(epilogue=L.EPI_GLU, aux=torch.empty(m, n, device=dev, dtype=odt), bias=rnd(n), act=1)
+    if epi in ("dglu", "dglu0"):   # out = d(pre-activations) [m, 2n] from dh = a @ b and the saved pre-activations
+        out = torch.empty(m, 2 * n, device=dev, dtype=odt)
+        kw = dict(epilogue=L.EPI_DGLU, aux=rnd(m, 2 * n), act=int(epi == "dglu"), ldo=2 * n)
     fn = lambda: K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=m, N=n, K=k, out=out, algo=4, **kw)
     fn256 = lambda: K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=m, N=n, K=k, out=out, algo=3, **kw)
     ms = timeit(fn, 5 if NOREF else 20)

@@ -254,50 +254,82 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 // LDS row strides (bytes) for a [64][DHP] bf16 tile.
 //   ROWS: ds_read_b128 of 32 different rows at one column is conflict-free when stride/4 = 4 (mod 8) dwords
-//   COLS: ds_read_b64_tr_b16 blocks of 4 rows are conflict-free when stride/4 = 16 or 48 (mod 64) dwords
+//   COLS: ds_read_b64_tr_b16 blocks of 4 rows are conflict-free when stride/4 = 16 or 48 (mod 64) dwords.
+// A tile that is read both ways uses the COLS stride and stores 16-byte chunk c of row r at chunk position
+// c ^ ((r >> 2) & 3): the transposing reads still find 4 rows x 64 contiguous bytes on distinct banks (the 4 rows of a
+// read share (r >> 2) & 3), and the 16 rows one ds_read_b128 lane group covers now land on 16 different bank quads.
 template <int DHP> struct Strides {
   static constexpr int ROWS = DHP * 2 + 16;
   static constexpr int COLS = (DHP == 96) ? 192 : DHP * 2 + 64;
 };
 
-// global [rows x Dh] (row stride ss) -> registers, zero filled outside (row < nrows, d < Dh); NCH chunks/thread
+// Operand rows come through buffer loads: a row at or beyond S starts past the descriptor's size and reads as zeros,
+// a 16-byte chunk beyond the head dimension is given an offset past any size (the host keeps S * stride below 2^30 B).
+constexpr uint32_t OOB_OFF = 0xC0000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const bf16* g, int64_t ss, int S, int Dh) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)(((int64_t)(S - 1) * ss + Dh) * 2), 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// global [64 rows x Dh] tiles (row stride ss) -> registers; NCH 16-byte chunks per thread
+template <int NCH> struct TileSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t off[NCH];     // this thread's chunks inside tile 0
+  uint32_t tile_bytes;   // 64 rows
+};
 template <int DHP, int NT, int NCH>
-__device__ __forceinline__ void stage_load(uint4 (&r)[NCH], const bf16* __restrict__ g, int64_t ss, int64_t row0,
-                                           int64_t nrows, int Dh, int tid) {
+__device__ __forceinline__ TileSrc<NCH> make_tilesrc(const bf16* g, int64_t ss, int S, int Dh, int tid) {
   constexpr int CPR = DHP / 8;
+  TileSrc<NCH> t;
+  t.rsrc = rows_rsrc(g, ss, S, Dh);
+  t.tile_bytes = (uint32_t)(64 * ss * 2);
 #pragma unroll
   for (int i = 0; i < NCH; i++) {
     const int c = tid + i * NT;
     const int row = c / CPR, dc = c % CPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (c < 64 * CPR && row0 + row < nrows && dc * 8 < Dh) v = *(const uint4*)(g + (row0 + row) * ss + dc * 8);
-    r[i] = v;
+    t.off[i] = (c < 64 * CPR && dc * 8 < Dh) ? (uint32_t)((row * ss + dc * 8) * 2) : OOB_OFF;
   }
+  return t;
 }
-template <int DHP, int NT, int NCH, int STRIDE>
+template <int NCH>
+__device__ __forceinline__ void stage_load(uint4 (&r)[NCH], const TileSrc<NCH>& t, int tile) {
+  const uint32_t base = (uint32_t)tile * t.tile_bytes;
+#pragma unroll
+  for (int i = 0; i < NCH; i++) r[i] = buf_load16(t.rsrc, t.off[i] + base);
+}
+template <int DHP, int NT, int NCH, int STRIDE, bool SWZ>
 __device__ __forceinline__ void stage_store(const uint4 (&r)[NCH], char* s, int tid) {
   constexpr int CPR = DHP / 8;
 #pragma unroll
   for (int i = 0; i < NCH; i++) {
     const int c = tid + i * NT;
-    if (c < 64 * CPR) *(uint4*)(s + (c / CPR) * STRIDE + (c % CPR) * 16) = r[i];
+    const int row = c / CPR, dc = c % CPR;
+    const int pc = SWZ ? (dc ^ ((row >> 2) & 3)) : dc;
+    if (c < 64 * CPR) *(uint4*)(s + row * STRIDE + pc * 16) = r[i];
   }
 }
 
-// row-wise operand fragment: element j = tile[r0 + (lane&31)][ks*16 + 8*(lane>>5) + j]
-template <int STRIDE>
+// row-wise operand fragment: element j = tile[r0 + (lane&31)][ks*16 + 8*(lane>>5) + j]   (r0 a multiple of 32)
+template <int STRIDE, bool SWZ>
 __device__ __forceinline__ bf16x8 frag_rows(const char* s, int r0, int ks, int lane) {
-  return *(const bf16x8*)(s + (r0 + (lane & 31)) * STRIDE + (ks * 16 + 8 * (lane >> 5)) * 2);
+  const int row = r0 + (lane & 31);
+  int chunk = ks * 2 + (lane >> 5);
+  if (SWZ) chunk ^= (row >> 2) & 3;
+  return *(const bf16x8*)(s + row * STRIDE + chunk * 16);
 }
 // column-wise operand fragment for a product whose other operand is an accumulator tile converted in
 // place: element j = tile[r0 + 16*s2 + 8*(j>>2) + 4*(lane>>5) + (j&3)][c0 + (lane&31)]
-template <int STRIDE>
+template <int STRIDE, bool SWZ>
 __device__ __forceinline__ bf16x8 frag_cols(const char* s, int r0, int s2, int c0, int lane) {
   const int row = r0 + 16 * s2 + 4 * (lane >> 5) + ((lane & 15) >> 2);
   const int col = c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const char* p = s + row * STRIDE + col * 2;
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 8 * STRIDE));
+  const int chunk = col >> 3, sub = (col & 7) * 2;
+  const int c_lo = SWZ ? (chunk ^ ((row >> 2) & 3)) : chunk;
+  const int c_hi = SWZ ? (chunk ^ (((row + 8) >> 2) & 3)) : chunk;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + row * STRIDE + c_lo * 16 + sub));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + (row + 8) * STRIDE + c_hi * 16 + sub));
   bf16x8 f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -312,155 +344,237 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s2) {
 }
 // stationary-side fragments straight from global: element j = g[row][ks*16 + 8*(lane>>5) + j]
 template <int DHP>
-__device__ __forceinline__ void load_stationary(bf16x8 (&f)[DHP / 16], const bf16* __restrict__ g, int64_t ss, int64_t row,
-                                                bool valid, int Dh, int lane) {
+__device__ __forceinline__ void load_stationary(bf16x8 (&f)[DHP / 16], const bf16* __restrict__ g, int64_t ss, int row,
+                                                int S, int Dh, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = rows_rsrc(g, ss, S, Dh);
 #pragma unroll
   for (int ks = 0; ks < DHP / 16; ks++) {
     const int d = ks * 16 + 8 * (lane >> 5);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (valid && d < Dh) v = *(const uint4*)(g + row * ss + d);
-    f[ks] = __builtin_bit_cast(bf16x8, v);
+    f[ks] = __builtin_bit_cast(bf16x8, buf_load16(rs, (row < S && d < Dh) ? (uint32_t)((row * ss + d) * 2) : OOB_OFF));
   }
 }
-// row index of accumulator register r inside a 32x32 tile
-__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+// row index of accumulator register r inside a 32x32 tile (plus 4 for the upper 32 lanes)
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
-// store a transposed accumulator set X^T[d][row] (row on the lane) as row-major bf16 rows, optional scale
+// lanes l and l+32 exchange: returns {lower halves of a and b side by side, upper halves side by side}
+__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+__device__ __forceinline__ float max_xor32(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  swap32(a, b);
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) bf16 bf16x2_t;
+  bf16x2_t t;
+  t[0] = (bf16)lo;
+  t[1] = (bf16)hi;
+  return __builtin_bit_cast(uint32_t, t);
+}
+
+// store a transposed accumulator set X^T[d][row] (row on the lane) as row-major bf16 rows, optional scale.  A lane holds
+// 4 consecutive d per register quad and its partner lane (+-32) the next 4; quads of neighbouring groups are traded so
+// that every lane writes 8 consecutive d with one 16-byte store.
 template <int DHP>
 __device__ __forceinline__ void store_rows(bf16* __restrict__ dst, const f32x16 (&acc)[DHP / 32], float mul, int Dh, int lane) {
 #pragma unroll
   for (int dt = 0; dt < DHP / 32; dt++)
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int d = dt * 32 + 8 * g + 4 * (lane >> 5);
-      if (d < Dh) {
-        bf16x4 t;
-#pragma unroll
-        for (int j = 0; j < 4; j++) t[j] = (bf16)(acc[dt][4 * g + j] * mul);
-        *(bf16x4*)(dst + d) = t;
-      }
+    for (int h = 0; h < 2; h++) {
+      uint32_t a01 = pack_bf16(acc[dt][8 * h + 0] * mul, acc[dt][8 * h + 1] * mul);
+      uint32_t a23 = pack_bf16(acc[dt][8 * h + 2] * mul, acc[dt][8 * h + 3] * mul);
+      uint32_t b01 = pack_bf16(acc[dt][8 * h + 4] * mul, acc[dt][8 * h + 5] * mul);
+      uint32_t b23 = pack_bf16(acc[dt][8 * h + 6] * mul, acc[dt][8 * h + 7] * mul);
+      swap32(a01, b01);
+      swap32(a23, b23);
+      const int d = dt * 32 + 16 * h + 8 * (lane >> 5);
+      if (d < Dh) *(uint4*)(dst + d) = make_uint4(a01, a23, b01, b23);
     }
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // one v_exp_f32
 
 #define ZERO16 {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
+#define MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+
+// ---- forward ------------------------------------------------------------------------------------
+// One 64-key tile (HALVES = 2) or its first 32 keys (HALVES = 1) against a wave's 32 queries.  Scores are kept
+// transposed, S^T[key][query], so a lane owns one query: row statistics need one exchange with the partner lane, and the
+// exponentiated tile is already laid out as the B operand of the P V product.  The row sum is taken by the matrix
+// unit (a ones operand), on the same bf16-rounded probabilities that multiply V.
+template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS>
+__device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const char* sV, const bf16x8 (&qf)[DHP / 16],
+                                         f32x16 (&oacc)[DHP / 32], f32x16& lacc, float& m, float c, int k0, int S,
+                                         uint64_t rbase, int lane) {
+  const f32x16 zero = ZERO16;
+  const int rowoff = 4 * (lane >> 5);
+  f32x16 sacc[HALVES];
+#pragma unroll
+  for (int st = 0; st < HALVES; st++) {
+    sacc[st] = MFMA(frag_rows<KS, false>(sK, st * 32, 0, lane), qf[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < DHP / 16; ks++) sacc[st] = MFMA(frag_rows<KS, false>(sK, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
+  }
+  if (PARTIAL) {   // keys at or beyond S (only in the last half of the last tile) get probability 0
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      if (k0 + (HALVES - 1) * 32 + acc_row(r) + rowoff >= S) sacc[HALVES - 1][r] = -INFINITY;
+  }
+  float mx = sacc[0][0];
+#pragma unroll
+  for (int st = 0; st < HALVES; st++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[st][r]);
+  mx = max_xor32(mx);
+  // The reference maximum m only has to keep the exponentials in range, so it is moved (and O, l rescaled) only when
+  // some query's tile maximum exceeds it by more than 2^8 in the exponent; all probabilities of a row share one m.
+  if (__any(mx * c > m * c + 8.f)) {
+    const float mnew = fmaxf(m, mx);
+    const float alpha = fast_exp2((m - mnew) * c);
+    lacc[0] *= alpha;     // only element 0 of the sum tile is ever read
+#pragma unroll
+    for (int dt = 0; dt < DHP / 32; dt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
+    m = mnew;
+  }
+  const float nmc = -m * c;
+#pragma unroll
+  for (int st = 0; st < HALVES; st++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) sacc[st][r] = fast_exp2(fmaf(sacc[st][r], c, nmc));
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; j++) ones[j] = (bf16)1.f;
+  // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+  for (int st = 0; st < HALVES; st++)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      bf16x8 pf = acc_to_frag(sacc[st], s2);
+      lacc = MFMA(ones, pf, lacc, 0, 0, 0);
+      if (DROP) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int key = k0 + st * 32 + acc_row(8 * s2 + j) + rowoff;
+          if (rng_u32(p.seed, rbase + (uint64_t)key) < p.thr) sacc[st][8 * s2 + j] = 0.f;
+          else sacc[st][8 * s2 + j] *= p.keep_scale;
+        }
+        pf = acc_to_frag(sacc[st], s2);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DHP / 32; dt++)
+        oacc[dt] = MFMA(frag_cols<VS, false>(sV, st * 32, s2, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+    }
+}
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_fwd_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
-  constexpr int KS = Strides<DHP>::ROWS, VS = Strides<DHP>::COLS;
-  __shared__ __attribute__((aligned(16))) char smem[64 * KS + 64 * VS];
-  char* sK = smem;
-  char* sV = smem + 64 * KS;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh, S = (int)p.S;
+  constexpr int KS = Strides<DHP>::ROWS, VS = Strides<DHP>::COLS, TILE = 64 * KS + 64 * VS;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];   // double buffer: one barrier per key tile
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int qrow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
-  const bool qv = qrow < S;
-  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;
+  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;   // else this wave only helps staging
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
 
+  const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.q_ss, S, Dh, tid);
+  const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.q_ss, S, Dh, tid);
+  uint4 rk[NCH], rv[NCH];
+  stage_load(rk, ksrc, 0);
+  stage_load(rv, vsrc, 0);
   bf16x8 qf[DHP / 16];
-  load_stationary<DHP>(qf, qp, p.q_ss, qrow, qv, Dh, lane);
+  load_stationary<DHP>(qf, qp, p.q_ss, qrow, S, Dh, lane);
   const f32x16 zero = ZERO16;
-  f32x16 oacc[DHP / 32];
+  f32x16 oacc[DHP / 32], lacc = zero;
 #pragma unroll
   for (int dt = 0; dt < DHP / 32; dt++) oacc[dt] = zero;
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY;
   const float c = p.scale * LOG2E;
   const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.S;
-  const int rowoff = 4 * (lane >> 5);   // accumulator register r holds key row (r&3) + 8*(r>>2) + rowoff
+  stage_store<DHP, NT, NCH, KS, false>(rk, smem, tid);
+  stage_store<DHP, NT, NCH, VS, false>(rv, smem + 64 * KS, tid);
+  __syncthreads();
 
-  uint4 rk[NCH], rv[NCH];
-  stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, 0, p.S, Dh, tid);
-  stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, 0, p.S, Dh, tid);
-  for (int k0 = 0; k0 < S; k0 += 64) {
+  // full 64-key tiles, then the tail tile (staged by the last iteration, or before the loop when S < 64)
+  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  for (int t = 0; t < nfull; t++) {
+    const char* sK = smem + (t & 1) * TILE;
+    const char* sV = sK + 64 * KS;
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      stage_load(rk, ksrc, t + 1);
+      stage_load(rv, vsrc, t + 1);
+    }
+    if (wave_on) fwd_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, t * 64, S, rbase, lane);
+    if (more) {
+      char* nK = smem + ((t + 1) & 1) * TILE;
+      stage_store<DHP, NT, NCH, KS, false>(rk, nK, tid);
+      stage_store<DHP, NT, NCH, VS, false>(rv, nK + 64 * KS, tid);
+    }
     __syncthreads();
-    stage_store<DHP, NT, NCH, KS>(rk, sK, tid);
-    stage_store<DHP, NT, NCH, VS>(rv, sV, tid);
-    __syncthreads();
-    if (k0 + 64 < S) {
-      stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, k0 + 64, p.S, Dh, tid);
-      stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, k0 + 64, p.S, Dh, tid);
+  }
+  if (nfull < ntiles && wave_on) {
+    const char* sK = smem + (nfull & 1) * TILE;
+    const char* sV = sK + 64 * KS;
+    if (S - nfull * 64 > 32) fwd_tile<DHP, 2, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, S, rbase, lane);
+    else fwd_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, S, rbase, lane);
+  }
+  if (qrow >= S) return;
+  const float l = lacc[0];
+  store_rows<DHP>((bf16*)p.o + b * p.o_sb + h * p.o_sh + (int64_t)qrow * p.o_ss, oacc, 1.f / l, Dh, lane);
+  if (lane < 32) p.lse[(b * p.H + h) * p.S + qrow] = m * p.scale + __logf(l);
+}
+
+// ---- backward: dQ -------------------------------------------------------------------------------
+template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS>
+__device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const char* sV, const bf16x8 (&qf)[DHP / 16],
+                                        const bf16x8 (&gf)[DHP / 16], f32x16 (&dqacc)[DHP / 32], float nlse2, float delta,
+                                        float c, int k0, int S, uint64_t rbase, int lane) {
+  const f32x16 zero = ZERO16;
+  const int rowoff = 4 * (lane >> 5);
+#pragma unroll
+  for (int st = 0; st < HALVES; st++) {
+    f32x16 sacc = MFMA(frag_rows<KS, true>(sK, st * 32, 0, lane), qf[0], zero, 0, 0, 0);
+    f32x16 pacc = MFMA(frag_rows<VS, false>(sV, st * 32, 0, lane), gf[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < DHP / 16; ks++) {
+      sacc = MFMA(frag_rows<KS, true>(sK, st * 32, ks, lane), qf[ks], sacc, 0, 0, 0);
+      pacc = MFMA(frag_rows<VS, false>(sV, st * 32, ks, lane), gf[ks], pacc, 0, 0, 0);
     }
-    if (!wave_on) continue;                    // this wave's 32 queries are all beyond S: it only helps staging
-    const bool two = k0 + 32 < S;              // the second 32-key half of the tile holds valid keys (wave-uniform)
-    // scores: sacc[st][r] = S^T[key = k0 + st*32 + row(r)][query = lane&31]
-    f32x16 sacc[2];
+    // dS^T[key][q] = P (dP - delta); keys beyond S contribute nothing
 #pragma unroll
-    for (int st = 0; st < 2; st++) {
-      sacc[st] = zero;
-      if (st == 0 || two) {
-#pragma unroll
-        for (int ks = 0; ks < DHP / 16; ks++)
-          sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KS>(sK, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
-      }
+    for (int r = 0; r < 16; r++) {
+      const int key = k0 + st * 32 + acc_row(r) + rowoff;
+      float pr = fast_exp2(fmaf(sacc[r], c, nlse2));
+      if (PARTIAL && st == HALVES - 1) pr = key < S ? pr : 0.f;
+      float dp = pacc[r];
+      if (DROP) dp = rng_u32(p.seed, rbase + (uint64_t)key) >= p.thr ? dp * p.keep_scale : 0.f;
+      sacc[r] = pr * (dp - delta);
     }
-    if (k0 + 64 > S) {                         // last, partial tile: keys beyond S get probability 0
 #pragma unroll
-      for (int st = 0; st < 2; st++)
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          if (k0 + st * 32 + (r & 3) + 8 * (r >> 2) + rowoff >= S) sacc[st][r] = -INFINITY;
-    }
-    float mx = m;
-#pragma unroll
-    for (int st = 0; st < 2; st++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[st][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float nmc = -mx * c;
-    float psum = 0.f;
-#pragma unroll
-    for (int st = 0; st < 2; st++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float pr = fast_exp2(fmaf(sacc[st][r], c, nmc));
-        psum += pr;
-        if (DROP) {
-          const uint64_t key = (uint64_t)(k0 + st * 32 + (r & 3) + 8 * (r >> 2) + rowoff);
-          pr = rng_u32(p.seed, rbase + key) >= p.thr ? pr * p.keep_scale : 0.f;
-        }
-        sacc[st][r] = pr;
-      }
-    if (__any(mx != m)) {                      // running max moved for some query of this wave: rescale O and l
-      const float alpha = fast_exp2((m - mx) * c);
-      l *= alpha;
+    for (int s2 = 0; s2 < 2; s2++) {
+      const bf16x8 df = acc_to_frag(sacc, s2);
 #pragma unroll
       for (int dt = 0; dt < DHP / 32; dt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) oacc[dt][r] *= alpha;
-      m = mx;
+        dqacc[dt] = MFMA(frag_cols<KS, true>(sK, st * 32, s2, dt * 32, lane), df, dqacc[dt], 0, 0, 0);
     }
-    l += psum;
-    // O^T[d][q] += V^T[d][key] P^T[key][q]
-#pragma unroll
-    for (int st = 0; st < 2; st++)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        if (st == 1 && !two) continue;
-        const bf16x8 pf = acc_to_frag(sacc[st], s2);
-#pragma unroll
-        for (int dt = 0; dt < DHP / 32; dt++)
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<VS>(sV, st * 32, s2, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
-      }
   }
-  l += __shfl_xor(l, 32, 64);
-  if (!qv) return;
-  store_rows<DHP>((bf16*)p.o + b * p.o_sb + h * p.o_sh + (int64_t)qrow * p.o_ss, oacc, 1.f / l, Dh, lane);
-  if (lane < 32) p.lse[(b * p.H + h) * p.S + qrow] = m * p.scale + logf(l);
 }
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_dq_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
-  constexpr int KS = Strides<DHP>::COLS, VS = Strides<DHP>::ROWS;  // K is read both ways, V row-wise only
-  __shared__ __attribute__((aligned(16))) char smem[64 * KS + 64 * VS];
-  char* sK = smem;
-  char* sV = smem + 64 * KS;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh, S = (int)p.S;
+  constexpr int KS = Strides<DHP>::COLS, VS = Strides<DHP>::ROWS;  // K is read both ways (swizzled), V row-wise only
+  constexpr int TILE = 64 * KS + 64 * VS;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int qrow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
   const bool qv = qrow < S;
@@ -470,9 +584,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
   const bf16* gp = (const bf16*)p.dout + b * p.o_sb + h * p.o_sh;
 
+  const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.q_ss, S, Dh, tid);
+  const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.q_ss, S, Dh, tid);
+  uint4 rk[NCH], rv[NCH];
+  stage_load(rk, ksrc, 0);
+  stage_load(rv, vsrc, 0);
   bf16x8 qf[DHP / 16], gf[DHP / 16];
-  load_stationary<DHP>(qf, qp, p.q_ss, qrow, qv, Dh, lane);
-  load_stationary<DHP>(gf, gp, p.o_ss, qrow, qv, Dh, lane);
+  load_stationary<DHP>(qf, qp, p.q_ss, qrow, S, Dh, lane);
+  load_stationary<DHP>(gf, gp, p.o_ss, qrow, S, Dh, lane);
   const int64_t srow = (b * p.H + h) * p.S + qrow;
   const float nlse2 = qv ? -p.lse[srow] * LOG2E : 0.f;
   // delta = rowsum(dO * O), computed here (each half-wave holds half of the row) and published for attn_dkdv_k,
@@ -480,7 +599,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   float delta = 0.f;
   {
     bf16x8 of[DHP / 16];
-    load_stationary<DHP>(of, (const bf16*)p.o + b * p.o_sb + h * p.o_sh, p.o_ss, qrow, qv, Dh, lane);
+    load_stationary<DHP>(of, (const bf16*)p.o + b * p.o_sb + h * p.o_sh, p.o_ss, qrow, S, Dh, lane);
 #pragma unroll
     for (int ks = 0; ks < DHP / 16; ks++)
 #pragma unroll
@@ -490,87 +609,110 @@ __global__ __launch_bounds__(NW * 64) void attn_dq_k(AttnP p) {
   }
   const float c = p.scale * LOG2E;
   const uint64_t rbase = (uint64_t)srow * p.S;
-  const int rowoff = 4 * (lane >> 5);
   const f32x16 zero = ZERO16;
   f32x16 dqacc[DHP / 32];
 #pragma unroll
   for (int dt = 0; dt < DHP / 32; dt++) dqacc[dt] = zero;
+  stage_store<DHP, NT, NCH, KS, true>(rk, smem, tid);
+  stage_store<DHP, NT, NCH, VS, false>(rv, smem + 64 * KS, tid);
+  __syncthreads();
 
-  uint4 rk[NCH], rv[NCH];
-  stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, 0, p.S, Dh, tid);
-  stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, 0, p.S, Dh, tid);
-  for (int k0 = 0; k0 < S; k0 += 64) {
-    __syncthreads();
-    stage_store<DHP, NT, NCH, KS>(rk, sK, tid);
-    stage_store<DHP, NT, NCH, VS>(rv, sV, tid);
-    __syncthreads();
-    if (k0 + 64 < S) {
-      stage_load<DHP, NT, NCH>(rk, kp, p.q_ss, k0 + 64, p.S, Dh, tid);
-      stage_load<DHP, NT, NCH>(rv, vp, p.q_ss, k0 + 64, p.S, Dh, tid);
+  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  for (int t = 0; t < nfull; t++) {
+    const char* sK = smem + (t & 1) * TILE;
+    const char* sV = sK + 64 * KS;
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      stage_load(rk, ksrc, t + 1);
+      stage_load(rv, vsrc, t + 1);
     }
-    if (!wave_on) continue;
-#pragma unroll
-    for (int st = 0; st < 2; st++) {
-      if (st == 1 && k0 + 32 >= S) continue;   // no valid key in the second half of the last tile
-      f32x16 sacc = zero, pacc = zero;
-#pragma unroll
-      for (int ks = 0; ks < DHP / 16; ks++) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<KS>(sK, st * 32, ks, lane), qf[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<VS>(sV, st * 32, ks, lane), gf[ks], pacc, 0, 0, 0);
-      }
-      // dS^T[key][q] = P (dP - delta); keys beyond S contribute nothing
-      const bool partial = k0 + st * 32 + 32 > S;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = k0 + st * 32 + (r & 3) + 8 * (r >> 2) + rowoff;
-        float pr = fast_exp2(fmaf(sacc[r], c, nlse2));
-        if (partial) pr = key < S ? pr : 0.f;
-        float dp = pacc[r];
-        if (DROP) dp = rng_u32(p.seed, rbase + (uint64_t)key) >= p.thr ? dp * p.keep_scale : 0.f;
-        sacc[r] = pr * (dp - delta);
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        const bf16x8 df = acc_to_frag(sacc, s2);
-#pragma unroll
-        for (int dt = 0; dt < DHP / 32; dt++)
-          dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<KS>(sK, st * 32, s2, dt * 32, lane), df, dqacc[dt], 0, 0, 0);
-      }
+    if (wave_on) dq_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, t * 64, S, rbase, lane);
+    if (more) {
+      char* nK = smem + ((t + 1) & 1) * TILE;
+      stage_store<DHP, NT, NCH, KS, true>(rk, nK, tid);
+      stage_store<DHP, NT, NCH, VS, false>(rv, nK + 64 * KS, tid);
     }
+    __syncthreads();
+  }
+  if (nfull < ntiles && wave_on) {
+    const char* sK = smem + (nfull & 1) * TILE;
+    const char* sV = sK + 64 * KS;
+    if (S - nfull * 64 > 32) dq_tile<DHP, 2, true, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, nfull * 64, S, rbase, lane);
+    else dq_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, nfull * 64, S, rbase, lane);
   }
   if (!qv) return;
   store_rows<DHP>((bf16*)p.dq + b * p.g_sb + h * p.g_sh + (int64_t)qrow * p.g_ss, dqacc, p.scale, Dh, lane);
 }
 
+// ---- backward: dK, dV ---------------------------------------------------------------------------
+// Query rows at or beyond S carry -lse = -inf, so their probability (and with it dS) is exactly 0.
+template <int DHP, int HALVES, bool DROP, int QS>
+__device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const char* sG, const float* sL,
+                                          const bf16x8 (&kf)[DHP / 16], const bf16x8 (&vf)[DHP / 16],
+                                          f32x16 (&dkacc)[DHP / 32], f32x16 (&dvacc)[DHP / 32], float c, int q0,
+                                          int64_t sbase, int krow, int lane) {
+  const f32x16 zero = ZERO16;
+  const int rowoff = 4 * (lane >> 5);
+#pragma unroll
+  for (int st = 0; st < HALVES; st++) {
+    // sacc[r] = S[q = q0 + st*32 + row(r)][key = lane&31], pacc likewise for dP
+    f32x16 sacc = MFMA(frag_rows<QS, true>(sQ, st * 32, 0, lane), kf[0], zero, 0, 0, 0);
+    f32x16 pacc = MFMA(frag_rows<QS, true>(sG, st * 32, 0, lane), vf[0], zero, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < DHP / 16; ks++) {
+      sacc = MFMA(frag_rows<QS, true>(sQ, st * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
+      pacc = MFMA(frag_rows<QS, true>(sG, st * 32, ks, lane), vf[ks], pacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int ql = st * 32 + 8 * g + rowoff;
+      const f32x4 l4 = *(const f32x4*)(sL + ql);
+      const f32x4 d4 = *(const f32x4*)(sL + 64 + ql);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = 4 * g + j;
+        const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
+        float pd = pr, dp = pacc[r];
+        if (DROP) {
+          const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.S + (uint64_t)krow) >= p.thr;
+          pd = keep ? pr * p.keep_scale : 0.f;
+          dp = keep ? dp * p.keep_scale : 0.f;
+        }
+        sacc[r] = pd;                  // P (dropped) for dV
+        pacc[r] = pr * (dp - d4[j]);   // dS for dK
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      const bf16x8 pf = acc_to_frag(sacc, s2);
+      const bf16x8 df = acc_to_frag(pacc, s2);
+#pragma unroll
+      for (int dt = 0; dt < DHP / 32; dt++) {
+        dvacc[dt] = MFMA(frag_cols<QS, true>(sG, st * 32, s2, dt * 32, lane), pf, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = MFMA(frag_cols<QS, true>(sQ, st * 32, s2, dt * 32, lane), df, dkacc[dt], 0, 0, 0);
+      }
+    }
+  }
+}
+
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_dkdv_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
-  constexpr int QS = Strides<DHP>::COLS;  // Q and dO tiles are read both ways
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * QS + 512];
-  char* sQ = smem;
-  char* sG = smem + 64 * QS;
-  float* sL = (float*)(smem + 2 * 64 * QS);  // -lse*log2e [64], delta[64]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, Dh = (int)p.Dh, S = (int)p.S;
+  constexpr int QS = Strides<DHP>::COLS;   // Q and dO tiles are read both ways (swizzled)
+  constexpr int TILE = 2 * 64 * QS + 512;  // Q, dO, then -lse*log2e [64] and delta [64]
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
   const int64_t b = blockIdx.z, h = blockIdx.y;
   const int krow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
-  const bool kvalid = krow < S;
   const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
   const bf16* gp = (const bf16*)p.dout + b * p.o_sb + h * p.o_sh;
-
-  bf16x8 kf[DHP / 16], vf[DHP / 16];
-  load_stationary<DHP>(kf, kp, p.q_ss, krow, kvalid, Dh, lane);
-  load_stationary<DHP>(vf, vp, p.q_ss, krow, kvalid, Dh, lane);
   const int64_t sbase = (b * p.H + h) * p.S;
-  const float c = p.scale * LOG2E;
-  const int rowoff = 4 * (lane >> 5);
-  const f32x16 zero = ZERO16;
-  f32x16 dkacc[DHP / 32], dvacc[DHP / 32];
-#pragma unroll
-  for (int dt = 0; dt < DHP / 32; dt++) { dkacc[dt] = zero; dvacc[dt] = zero; }
 
+  const TileSrc<NCH> qsrc = make_tilesrc<DHP, NT, NCH>(qp, p.q_ss, S, Dh, tid);
+  const TileSrc<NCH> gsrc = make_tilesrc<DHP, NT, NCH>(gp, p.o_ss, S, Dh, tid);
   uint4 rq[NCH], rg[NCH];
   float rl = 0.f;
   // rows beyond S: -lse = -inf makes their probability exactly 0
@@ -580,66 +722,54 @@ __global__ __launch_bounds__(NW * 64) void attn_dkdv_k(AttnP p) {
       rl = qq < S ? (tid < 64 ? -p.lse[sbase + qq] * LOG2E : p.delta[sbase + qq]) : (tid < 64 ? -INFINITY : 0.f);
     }
   };
-  stage_load<DHP, NT, NCH>(rq, qp, p.q_ss, 0, p.S, Dh, tid);
-  stage_load<DHP, NT, NCH>(rg, gp, p.o_ss, 0, p.S, Dh, tid);
+  stage_load(rq, qsrc, 0);
+  stage_load(rg, gsrc, 0);
   load_row_consts(0);
-  for (int q0 = 0; q0 < S; q0 += 64) {
-    __syncthreads();
-    stage_store<DHP, NT, NCH, QS>(rq, sQ, tid);
-    stage_store<DHP, NT, NCH, QS>(rg, sG, tid);
-    if (tid < 128) sL[tid] = rl;
-    __syncthreads();
-    if (q0 + 64 < S) {
-      stage_load<DHP, NT, NCH>(rq, qp, p.q_ss, q0 + 64, p.S, Dh, tid);
-      stage_load<DHP, NT, NCH>(rg, gp, p.o_ss, q0 + 64, p.S, Dh, tid);
-      load_row_consts(q0 + 64);
+  bf16x8 kf[DHP / 16], vf[DHP / 16];
+  load_stationary<DHP>(kf, kp, p.q_ss, krow, S, Dh, lane);
+  load_stationary<DHP>(vf, vp, p.q_ss, krow, S, Dh, lane);
+  const float c = p.scale * LOG2E;
+  const f32x16 zero = ZERO16;
+  f32x16 dkacc[DHP / 32], dvacc[DHP / 32];
+#pragma unroll
+  for (int dt = 0; dt < DHP / 32; dt++) { dkacc[dt] = zero; dvacc[dt] = zero; }
+  stage_store<DHP, NT, NCH, QS, true>(rq, smem, tid);
+  stage_store<DHP, NT, NCH, QS, true>(rg, smem + 64 * QS, tid);
+  if (tid < 128) ((float*)(smem + 2 * 64 * QS))[tid] = rl;
+  __syncthreads();
+
+  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  for (int t = 0; t < nfull; t++) {
+    const char* sQ = smem + (t & 1) * TILE;
+    const char* sG = sQ + 64 * QS;
+    const float* sL = (const float*)(sQ + 2 * 64 * QS);
+    const bool more = t + 1 < ntiles;
+    if (more) {
+      stage_load(rq, qsrc, t + 1);
+      stage_load(rg, gsrc, t + 1);
+      load_row_consts((t + 1) * 64);
     }
-    if (!wave_on) continue;
-#pragma unroll
-    for (int st = 0; st < 2; st++) {
-      if (st == 1 && q0 + 32 >= S) continue;   // no valid query in the second half of the last tile
-      // sacc[r] = S[q = q0 + st*32 + row(r)][key = lane&31], pacc likewise for dP
-      f32x16 sacc = zero, pacc = zero;
-#pragma unroll
-      for (int ks = 0; ks < DHP / 16; ks++) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<QS>(sQ, st * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<QS>(sG, st * 32, ks, lane), vf[ks], pacc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int ql = st * 32 + 8 * g + rowoff;
-        const f32x4 l4 = *(const f32x4*)(sL + ql);
-        const f32x4 d4 = *(const f32x4*)(sL + 64 + ql);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int r = 4 * g + j;
-          const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
-          float pd = pr, dp = pacc[r];
-          if (DROP) {
-            const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.S + (uint64_t)krow) >= p.thr;
-            pd = keep ? pr * p.keep_scale : 0.f;
-            dp = keep ? dp * p.keep_scale : 0.f;
-          }
-          sacc[r] = pd;                  // P (dropped) for dV
-          pacc[r] = pr * (dp - d4[j]);   // dS for dK
-        }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        const bf16x8 pf = acc_to_frag(sacc, s2);
-        const bf16x8 df = acc_to_frag(pacc, s2);
-#pragma unroll
-        for (int dt = 0; dt < DHP / 32; dt++) {
-          dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<QS>(sG, st * 32, s2, dt * 32, lane), pf, dvacc[dt], 0, 0, 0);
-          dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<QS>(sQ, st * 32, s2, dt * 32, lane), df, dkacc[dt], 0, 0, 0);
-        }
-      }
+    if (wave_on) dkdv_tile<DHP, 2, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, t * 64, sbase, krow, lane);
+    if (more) {
+      char* nQ = smem + ((t + 1) & 1) * TILE;
+      stage_store<DHP, NT, NCH, QS, true>(rq, nQ, tid);
+      stage_store<DHP, NT, NCH, QS, true>(rg, nQ + 64 * QS, tid);
+      if (tid < 128) ((float*)(nQ + 2 * 64 * QS))[tid] = rl;
     }
+    __syncthreads();
   }
-  if (!kvalid) return;
+  if (nfull < ntiles && wave_on) {
+    const char* sQ = smem + (nfull & 1) * TILE;
+    const char* sG = sQ + 64 * QS;
+    const float* sL = (const float*)(sQ + 2 * 64 * QS);
+    if (S - nfull * 64 > 32) dkdv_tile<DHP, 2, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, nfull * 64, sbase, krow, lane);
+    else dkdv_tile<DHP, 1, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, nfull * 64, sbase, krow, lane);
+  }
+  if (krow >= S) return;
   store_rows<DHP>((bf16*)p.dk + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dkacc, p.scale, Dh, lane);
   store_rows<DHP>((bf16*)p.dv + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dvacc, 1.f, Dh, lane);
 }
+#undef MFMA
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -661,10 +791,12 @@ static bool attn_mfma_ok(const VitkAttn* a, bool bwd) {
   const int64_t st[] = {a->q_sb, a->q_sh, a->q_ss, a->o_sb, a->o_sh, a->o_ss};
   for (int64_t s : st) if (s % 8) return false;
   if (!al16(a->q) || !al16(a->k) || !al16(a->v)) return false;
-  if (((uintptr_t)a->o & 7)) return false;
+  if (!al16(a->o)) return false;
+  // operand rows are addressed with 32-bit byte offsets inside one (batch, head) slice
+  if (a->S * a->q_ss * 2 >= (1ll << 30) || a->S * a->o_ss * 2 >= (1ll << 30)) return false;
   if (bwd) {
-    if (a->dq_sb % 4 || a->dq_sh % 4 || a->dq_ss % 4) return false;
-    if (!al16(a->dout) || ((uintptr_t)a->dq & 7) || ((uintptr_t)a->dk & 7) || ((uintptr_t)a->dv & 7)) return false;
+    if (a->dq_sb % 8 || a->dq_sh % 8 || a->dq_ss % 8) return false;
+    if (!al16(a->dout) || !al16(a->dq) || !al16(a->dk) || !al16(a->dv)) return false;
   }
   return true;
 }
@@ -678,19 +810,28 @@ static int attn_validate(const VitkAttn* a, bool bwd) {
   if (bwd) VITK_REQUIRE(a->dout && a->dq && a->dk && a->dv && a->delta, "attn_bwd: null pointer");
   return 0;
 }
-// 4 waves (128 rows) per workgroup when that wastes little of the last block, else 2 waves (64 rows)
+// waves (32 rows each) per workgroup: the count in {4, 3, 2} that pads the sequence least; more waves share each staged tile
 static int pick_nw(int64_t S, int64_t Dh) {
-  if (const char* f = getenv("VITK_ATTN_NW")) return atoi(f) == 2 ? 2 : 4;
-  return (Dh > 96 || S % 128 == 0 || S % 128 > 64 || S >= 2048) ? 4 : 2;
+  if (const char* f = getenv("VITK_ATTN_NW")) { const int v = atoi(f); if (v >= 2 && v <= 4) return v; }
+  if (Dh > 96 || S >= 2048) return 4;
+  int best = 4;
+  int64_t best_pad = ceil_div(S, 128) * 128 - S;
+  for (int nw = 3; nw >= 2; nw--) {
+    const int64_t pad = ceil_div(S, nw * 32) * nw * 32 - S;
+    if (pad < best_pad) { best = nw; best_pad = pad; }
+  }
+  return best;
 }
 
 #define ATTN_DISPATCH(KERNEL, DHP, NW, grid, p, st)                                             \
   do {                                                                                          \
     if (p.thr) {                                                                                \
       if (NW == 4) hipLaunchKernelGGL((KERNEL<DHP, 4, true>), grid, dim3(256), 0, st, p);       \
+      else if (NW == 3) hipLaunchKernelGGL((KERNEL<DHP, 3, true>), grid, dim3(192), 0, st, p);  \
       else hipLaunchKernelGGL((KERNEL<DHP, 2, true>), grid, dim3(128), 0, st, p);               \
     } else {                                                                                    \
       if (NW == 4) hipLaunchKernelGGL((KERNEL<DHP, 4, false>), grid, dim3(256), 0, st, p);      \
+      else if (NW == 3) hipLaunchKernelGGL((KERNEL<DHP, 3, false>), grid, dim3(192), 0, st, p); \
       else hipLaunchKernelGGL((KERNEL<DHP, 2, false>), grid, dim3(128), 0, st, p);              \
     }                                                                                           \
   } while (0)

@@ -85,46 +85,50 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 }
 
 // ---- activations: vit/helpers.py:9-48 ------------------------------------------------------------
+// sigmoid(a*x) with one v_exp_f32 and one v_rcp_f32 (1 ulp each); exact 0 / 1 at the far ends
+__device__ __forceinline__ float fast_sigmoid(float x, float a = 1.f) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (-1.44269504088896340736f * a)));
+}
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {
     case VITK_ACT_RELU: return fmaxf(x, 0.f);
-    case VITK_ACT_SILU: return x / (1.f + __expf(-x));
+    case VITK_ACT_SILU: return x * fast_sigmoid(x);
     case VITK_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
     case VITK_ACT_SRELU: { float r = fmaxf(x, 0.f); return r * r; }
-    default: return x / (1.f + __expf(-1.702f * x));  // OPENSWIGLU: x * sigmoid(1.702 x)
+    default: return x * fast_sigmoid(x, 1.702f);  // OPENSWIGLU: x * sigmoid(1.702 x)
   }
 }
 __device__ __forceinline__ float act_grad(int act, float x) {
   switch (act) {
     case VITK_ACT_RELU: return x > 0.f ? 1.f : 0.f;
-    case VITK_ACT_SILU: { float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case VITK_ACT_SILU: { float s = fast_sigmoid(x); return s * (1.f + x * (1.f - s)); }
     case VITK_ACT_GELU: {
       float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
       float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
       return cdf + x * pdf;
     }
     case VITK_ACT_SRELU: return x > 0.f ? 2.f * x : 0.f;
-    default: { float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); }
+    default: { float s = fast_sigmoid(x, 1.702f); return s * (1.f + 1.702f * x * (1.f - s)); }
   }
 }
 
 // compile-time activation variants (loops over register arrays unroll only when the activation is a constant)
 template <int ACT> __device__ __forceinline__ float act_apply_t(float x) {
   if (ACT == VITK_ACT_RELU) return fmaxf(x, 0.f);
-  if (ACT == VITK_ACT_SILU) return x / (1.f + __expf(-x));
+  if (ACT == VITK_ACT_SILU) return x * fast_sigmoid(x);
   if (ACT == VITK_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
   if (ACT == VITK_ACT_SRELU) { const float r = fmaxf(x, 0.f); return r * r; }
-  return x / (1.f + __expf(-1.702f * x));
+  return x * fast_sigmoid(x, 1.702f);
 }
 template <int ACT> __device__ __forceinline__ float act_grad_t(float x) {
   if (ACT == VITK_ACT_RELU) return x > 0.f ? 1.f : 0.f;
-  if (ACT == VITK_ACT_SILU) { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+  if (ACT == VITK_ACT_SILU) { const float s = fast_sigmoid(x); return s * (1.f + x * (1.f - s)); }
   if (ACT == VITK_ACT_GELU) {
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
     return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
   }
   if (ACT == VITK_ACT_SRELU) return x > 0.f ? 2.f * x : 0.f;
-  const float s = 1.f / (1.f + __expf(-1.702f * x));
+  const float s = fast_sigmoid(x, 1.702f);
   return s * (1.f + 1.702f * x * (1.f - s));
 }
 #define ACT_SWITCH(code, ACT, ...)                                              \

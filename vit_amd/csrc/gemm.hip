@@ -37,9 +37,27 @@ constexpr int EPI_ACT = VITK_EPI_ACT, EPI_GLU = VITK_EPI_GLU, EPI_DACT = VITK_EP
 // (GLU forward pairs two column groups and has its own routine below.)
 // Per-row operands an epilogue reads from memory (residual row, position row, saved pre-activations).  They are
 // fetched for several rows before any of them is used, so the loads overlap instead of serialising on s_waitcnt.
+// Raw4<T>: 4 consecutive elements as loaded (no conversion until they are used, so a prefetched row costs 2 registers
+// for bf16 and 4 for fp32).
+template <class T> struct Raw4;
+template <> struct Raw4<float> {
+  float4 q;
+  __device__ __forceinline__ void load(const float* p) { q = *(const float4*)p; }
+  __device__ __forceinline__ float get(int j) const { return j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w; }
+};
+template <> struct Raw4<bf16> {
+  uint2 q;
+  __device__ __forceinline__ void load(const bf16* p) { q = *(const uint2*)p; }
+  __device__ __forceinline__ float get(int j) const {
+    const uint32_t w = j < 2 ? q.x : q.y;
+    return __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+};
+
 template <int MODE, class TO>
 struct EpiPre {
-  float a[4], b[4];
+  Raw4<bf16> a, b;   // PATCH: position row; DACT: pre-activations; DGLU: linear and gate pre-activations
+  Raw4<TO> r;        // RESIDUAL: the residual row
   int64_t row;
 };
 
@@ -49,31 +67,20 @@ struct EpiVec {
   static __device__ __forceinline__ void prefetch(const Epi& e, int64_t m, int64_t n, EpiPre<MODE, TO>& p) {
     if (MODE == VITK_EPI_RESIDUAL) {
       p.row = e.row_idx ? e.row_idx[m] : m;
-      Vec4<TO> r; r.load((const TO*)e.res + p.row * e.ldo + n);
-#pragma unroll
-      for (int j = 0; j < 4; j++) p.a[j] = r.v[j];
+      p.r.load((const TO*)e.res + p.row * e.ldo + n);
     } else if (MODE == VITK_EPI_PATCH) {
-      if (e.pos) {
-        Vec4<TI> ps; ps.load((const TI*)e.pos + (m % e.tokens) * e.N + n);
-#pragma unroll
-        for (int j = 0; j < 4; j++) p.a[j] = ps.v[j];
-      }
+      if (e.pos) p.a.load((const TI*)e.pos + (m % e.tokens) * e.N + n);
     } else if (MODE == EPI_DACT) {
-      Vec4<TI> pa; pa.load((const TI*)e.aux + m * e.N + n);
-#pragma unroll
-      for (int j = 0; j < 4; j++) p.a[j] = pa.v[j];
+      p.a.load((const TI*)e.aux + m * e.N + n);
     } else if (MODE == EPI_DGLU) {
-      Vec4<TI> lin, glu;
-      lin.load((const TI*)e.aux + m * 2 * e.N + n);
-      glu.load((const TI*)e.aux + m * 2 * e.N + e.N + n);
-#pragma unroll
-      for (int j = 0; j < 4; j++) { p.a[j] = lin.v[j]; p.b[j] = glu.v[j]; }
+      p.a.load((const TI*)e.aux + m * 2 * e.N + n);
+      p.b.load((const TI*)e.aux + m * 2 * e.N + e.N + n);
     }
   }
 
   // v = accumulators of columns n..n+3 of row m; bias/gamma = this lane's 4 columns (loaded once per tile)
   static __device__ __forceinline__ void apply(const Epi& e, int64_t m, int64_t n, float (&v)[4], const float (&bias)[4],
-                                               const float (&gamma)[4], EpiPre<MODE, TO>& p) {
+                                               const float (&gamma)[4], const EpiPre<MODE, TO>& p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) v[j] += bias[j];
     if (MODE == VITK_EPI_STORE) {
@@ -96,10 +103,10 @@ struct EpiVec {
       Vec4<TO> r;
       if (e.gamma) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) r.v[j] = p.a[j] + e.alpha * round_as<TO>(v[j] * gamma[j]);
+        for (int j = 0; j < 4; j++) r.v[j] = p.r.get(j) + e.alpha * round_as<TO>(v[j] * gamma[j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) r.v[j] = p.a[j] + e.alpha * v[j];
+        for (int j = 0; j < 4; j++) r.v[j] = p.r.get(j) + e.alpha * v[j];
       }
       r.store((TO*)e.out + p.row * e.ldo + n);
     } else if (MODE == VITK_EPI_PATCH) {
@@ -108,7 +115,7 @@ struct EpiVec {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         o.v[j] = round_as<TI>(v[j]);
-        if (e.pos) o.v[j] = round_as<TI>(o.v[j] + p.a[j]);
+        if (e.pos) o.v[j] = round_as<TI>(o.v[j] + p.a.get(j));
       }
       o.store((TO*)e.out + (b * e.seq + e.prefix + t) * e.ldo + n);
     } else if (MODE == EPI_ACT) {
@@ -136,32 +143,35 @@ struct EpiVec {
       }
       ACT_SWITCH(e.act, ACT, {
         _Pragma("unroll")
-        for (int j = 0; j < 4; j++) o.v[j] = v[j] * act_grad_t<ACT>(p.a[j]);
+        for (int j = 0; j < 4; j++) o.v[j] = v[j] * act_grad_t<ACT>(p.a.get(j));
       });
       o.store((TO*)e.out + m * e.ldo + n);
     } else {  // EPI_DGLU: p.a = linear pre-activation, p.b = gate pre-activation
       const int64_t F = e.N;
       Vec4<TO> dl, dg;
+      float pl[4], pg[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
+        pl[j] = p.a.get(j);
+        pg[j] = p.b.get(j);
         v[j] = round_as<TI>(v[j]);
         if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
         dl.v[j] = v[j];
         dg.v[j] = v[j];
         if (e.use_limit) {
-          const float l = p.a[j], gl = p.b[j];
+          const float l = pl[j], gl = pg[j];
           dl.v[j] = (l >= -e.limit && l <= e.limit) ? dl.v[j] : 0.f;
           dg.v[j] = (gl <= e.limit) ? dg.v[j] : 0.f;
-          p.a[j] = fminf(fmaxf(l, -e.limit), e.limit);
-          p.b[j] = fminf(gl, e.limit);
+          pl[j] = fminf(fmaxf(l, -e.limit), e.limit);
+          pg[j] = fminf(gl, e.limit);
         }
-        if (e.use_extra) p.a[j] = round_as<TI>(p.a[j] + e.extra);
+        if (e.use_extra) pl[j] = round_as<TI>(pl[j] + e.extra);
       }
       ACT_SWITCH(e.act, ACT, {
         _Pragma("unroll")
         for (int j = 0; j < 4; j++) {
-          dl.v[j] *= round_as<TI>(act_apply_t<ACT>(p.b[j]));
-          dg.v[j] *= p.a[j] * act_grad_t<ACT>(p.b[j]);
+          dl.v[j] *= round_as<TI>(act_apply_t<ACT>(pg[j]));
+          dg.v[j] *= pl[j] * act_grad_t<ACT>(pg[j]);
         }
       });
       dl.store((TO*)e.out + m * e.ldo + n);
@@ -428,20 +438,45 @@ struct EpiCols {  // per-lane column constants, loaded once per tile
   }
 };
 
-// one 32-row x 64-column slab of a wave's tile: a0 = columns 0..31, a1 = columns 32..63.  All waves of the block call
-// this the same number of times (it contains block barriers).
-template <int MODE, class TO, int PF = 4>
-__device__ __forceinline__ void epilogue_slab(const Epi& e, const EpiCols<MODE, TO>& cols, float* stg, const f32x16& a0,
-                                              const f32x16& a1, int64_t mbase, int64_t nwave, int64_t M, int64_t N,
-                                              int64_t split, float* __restrict__ partial, int lane) {
+// One 32-row x 64-column slab of a wave's tile, in three steps so that a kernel can issue the memory reads of a slab
+// (residual / position / saved pre-activation rows) well before it needs them:
+//   slab_prefetch  loads of the slab's 8 rows per lane;  slab_stage  accumulators -> the wave's own LDS slab;
+//   slab_finish    read back 4 consecutive columns per lane, apply the epilogue, store.
+// The staging slab belongs to one wave and LDS operations of a wave complete in order, so no barrier is needed
+// between the steps (the caller has one block barrier between the last main-loop LDS read and the first stage).
+template <int MODE, class TO>
+struct SlabPre { EpiPre<(MODE < 0 ? 0 : MODE), TO> r[8]; };
+
+template <int MODE>
+constexpr bool epi_reads_memory() { return MODE == VITK_EPI_RESIDUAL || MODE == VITK_EPI_PATCH || MODE == EPI_DACT || MODE == EPI_DGLU; }
+
+template <int MODE, class TO>
+__device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, TO>& cols, SlabPre<MODE, TO>& pre,
+                                              int64_t mbase, int64_t M, int64_t N, int lane) {
+  if (!epi_reads_memory<MODE>()) return;
   constexpr int EMODE = MODE < 0 ? 0 : MODE;
+  const int rr = lane >> 4;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int64_t m = mbase + it * 4 + rr;
+    if (m < M && cols.ncol < N) EpiVec<EMODE, TO>::prefetch(e, m, cols.ncol, pre.r[it]);
+  }
+}
+
+__device__ __forceinline__ void slab_stage(float* stg, const f32x16& a0, const f32x16& a1, int lane) {
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     stg[row * STG_LD + (lane & 31)] = a0[r];
     stg[row * STG_LD + 32 + (lane & 31)] = a1[r];
   }
-  __syncthreads();
+}
+
+template <int MODE, class TO>
+__device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO>& cols, const SlabPre<MODE, TO>& pre,
+                                            const float* stg, int64_t mbase, int64_t nwave, int64_t M, int64_t N,
+                                            int64_t split, float* __restrict__ partial, int lane) {
+  constexpr int EMODE = MODE < 0 ? 0 : MODE;
   const int64_t ncol = cols.ncol;
   if (MODE == EPI_GLU) {
     const int cv = lane & 7, rr = lane >> 3;
@@ -457,29 +492,17 @@ __device__ __forceinline__ void epilogue_slab(const Epi& e, const EpiCols<MODE, 
   } else {
     const int cv = lane & 15, rr = lane >> 4;
 #pragma unroll
-    for (int half = 0; half < 8 / PF; half++) {   // PF rows per lane at a time: fetch their memory operands, then finish them
-      EpiPre<EMODE, TO> pre[PF];
-      if (MODE != MODE_PARTIAL) {
-#pragma unroll
-        for (int it = 0; it < PF; it++) {
-          const int64_t m = mbase + (half * PF + it) * 4 + rr;
-          if (m < M && ncol < N) EpiVec<EMODE, TO>::prefetch(e, m, ncol, pre[it]);
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < PF; it++) {
-        const int row = (half * PF + it) * 4 + rr;
-        const int64_t m = mbase + row;
-        float v[4];
-        *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
-        if (m < M && ncol < N) {
-          if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + ncol) = *(const float4*)v;
-          else EpiVec<EMODE, TO>::apply(e, m, ncol, v, cols.bias0, cols.gam, pre[it]);
-        }
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 4 + rr;
+      const int64_t m = mbase + row;
+      float v[4];
+      *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
+      if (m < M && ncol < N) {
+        if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + ncol) = *(const float4*)v;
+        else EpiVec<EMODE, TO>::apply(e, m, ncol, v, cols.bias0, cols.gam, pre.r[it]);
       }
     }
   }
-  __syncthreads();
 }
 
 // blocks that share an XCD (bid % 8) get consecutive tile ids, so one L2 sees neighbouring tiles
@@ -489,7 +512,7 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
 }
 
 template <bool TA, bool TB, int MODE, class TO>
-__global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, const bf16* __restrict__ B, int64_t M,
+__global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A, const bf16* __restrict__ B, int64_t M,
                                                    int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
                                                    int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE_B];
@@ -514,17 +537,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
   const TileSrc srcA = make_src<TA, false>(A, lda, m0, M, kbeg, kend, K, tid);
   const TileSrc srcB = make_src<TB, MODE == EPI_GLU>(B, ldb, n0, N, kbeg, kend, K, tid);
   const int32_t klen_here = (int32_t)(kend - kbeg);
-  uint4 ra[4], rb[4];
-  load_tile<TA>(ra, srcA, 0);
-  load_tile<TB>(rb, srcB, 0);
-  for (int32_t kk = 0; kk < klen_here; kk += BK) {
-    store_tile<TA>(ra, sA, tid);
-    store_tile<TB>(rb, sB, tid);
-    __syncthreads();
-    if (kk + BK < klen_here) {
-      load_tile<TA>(ra, srcA, kk + BK);
-      load_tile<TB>(rb, srcB, kk + BK);
-    }
+  auto multiply = [&]() {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       bf16x8 af[2], bfr[2];
@@ -537,15 +550,38 @@ __global__ __launch_bounds__(256) void gemm_mfma_k(const bf16* __restrict__ A, c
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+  };
+  uint4 ra[4], rb[4];
+  load_tile<TA>(ra, srcA, 0);
+  load_tile<TB>(rb, srcB, 0);
+  for (int32_t kk = 0; kk + BK < klen_here; kk += BK) {
+    store_tile<TA>(ra, sA, tid);
+    store_tile<TB>(rb, sB, tid);
+    __syncthreads();
+    load_tile<TA>(ra, srcA, kk + BK);
+    load_tile<TB>(rb, srcB, kk + BK);
+    multiply();
     __syncthreads();
   }
-
+  // last K-step: the epilogue's memory operands for the first slab are requested before the multiply
+  store_tile<TA>(ra, sA, tid);
+  store_tile<TB>(rb, sB, tid);
+  __syncthreads();
   EpiCols<MODE, TO> cols;
   cols.init(e, n0 + wn * 64, N, lane);
+  SlabPre<MODE, TO> pre;
+  slab_prefetch<MODE, TO>(e, cols, pre, m0 + wm * 64, M, N, lane);
+  multiply();
+  __syncthreads();
+
   float* stg = (float*)smem + wid * (32 * STG_LD);
 #pragma unroll
-  for (int i = 0; i < 2; i++)
-    epilogue_slab<MODE, TO>(e, cols, stg, acc[i][0], acc[i][1], m0 + wm * 64 + i * 32, n0 + wn * 64, M, N, split, partial, lane);
+  for (int i = 0; i < 2; i++) {
+    const int64_t mbase = m0 + wm * 64 + i * 32;
+    if (i > 0) slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
+    slab_stage(stg, acc[i][0], acc[i][1], lane);
+    slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -665,9 +701,14 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
   EpiCols<MODE, TO> cols;
   cols.init(e, n0 + wn * 64, N, lane);
   float* stg = (float*)smem + wid * (32 * STG_LD);
+  SlabPre<MODE, TO> pre;
 #pragma unroll
-  for (int i = 0; i < 4; i++)
-    epilogue_slab<MODE, TO, 2>(e, cols, stg, acc[i][0], acc[i][1], m0 + wm * 128 + i * 32, n0 + wn * 64, M, N, split, partial, lane);
+  for (int i = 0; i < 4; i++) {
+    const int64_t mbase = m0 + wm * 128 + i * 32;
+    slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
+    slab_stage(stg, acc[i][0], acc[i][1], lane);
+    slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
+  }
 }
 
 template <int MODE, class TI, class TO>

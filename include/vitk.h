@@ -60,7 +60,8 @@ int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, cons
  *   VITK_EPI_RESIDUAL t = dropout(round(acc + bias[n])); aux[m,n] = t (optional);
  *                     out[row(m),n] = res[row(m),n] + alpha * gamma[n] * t      (gamma optional)
  *   VITK_EPI_PATCH    out[(m / tokens) * seq + prefix + m % tokens, n] = acc + bias[n] + pos[m % tokens, n]
- * algo: 0 = auto, 1 = portable scalar kernel (any dtype/shape), 2 = bf16 MFMA kernel (rejects what it cannot do).
+ * algo: 0 = auto, 1 = portable scalar kernel (any dtype/shape), 2 = bf16 MFMA kernel (rejects what it cannot do),
+ *       3 / 4 = MFMA kernel with the 256x256 / 128x128 tile forced (tuning and tests).
  * split-K (wgrad) partials live in `workspace` (vitk_gemm_workspace_bytes). */
 enum {
   VITK_EPI_STORE = 0, VITK_EPI_RESIDUAL = 1, VITK_EPI_PATCH = 2,
@@ -101,6 +102,8 @@ typedef struct VitkGemm {
   int32_t use_extra;
   float limit;
   float extra_bias;
+  void* a_colsum;        /* STORE with trans_a = 1 only, or NULL: a_colsum[m] = sum_k A[k,m], dtype out_dtype -- the bias
+                            gradient (autograd's dy.sum(0)) that accompanies a weight gradient dW = dy^T x, from the same pass */
 } VitkGemm;
 
 size_t vitk_gemm_workspace_bytes(const VitkGemm* g);

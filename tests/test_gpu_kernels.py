@@ -50,6 +50,27 @@ def test_mfma_gemm_exact_on_integers(layout, shape):
         assert torch.equal(out1, ref), f"algo {algo}: max err {(out1 - ref).abs().max().item()}"
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 4096), (200, 136, 328), (768, 512, 8192), (2304, 768, 2176)])
+def test_gemm_fused_bias_gradient_row_sums(shape):
+    """a_colsum[m] = sum_k A[k, m] from the weight-gradient pass (exact on small integers): every kernel family,
+    with and without split-K, fp32 and bf16 outputs."""
+    M, N, Kd = shape
+    g = torch.Generator().manual_seed(M + Kd)
+    A = torch.randint(-2, 3, (Kd, M), generator=g).float()
+    B = torch.randint(-2, 3, (Kd, N), generator=g).float()
+    ref, ref_sum = (A.t() @ B).to(DEV), A.sum(0).to(DEV)
+    a, b = A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16)
+    for od in (torch.float32, torch.bfloat16):
+        for algo in (0, 1, 3, 4):
+            out = torch.empty(M, N, device=DEV, dtype=od)
+            sums = torch.full((M,), float("nan"), device=DEV, dtype=od)
+            K.gemm(a, b, trans_a=True, trans_b=True, M=M, N=N, K=Kd, out=out, a_colsum=sums, algo=algo)
+            assert torch.equal(out.float(), ref.to(od).float()), f"algo {algo} {od}: product"
+            assert torch.equal(sums.float(), ref_sum.to(od).float()), f"algo {algo} {od}: sums {(sums.float() - ref_sum).abs().max().item()}"
+    with pytest.raises(RuntimeError, match="a_colsum"):
+        K.gemm(a.t().contiguous(), b, trans_a=False, trans_b=True, M=M, N=N, K=Kd, out=out, a_colsum=sums)
+
+
 def test_mfma_gemm_splitk_wgrad_shape():
     M, N, Kd = 256, 128, 4096  # few output tiles, long contraction -> split-K path
     g = torch.Generator().manual_seed(3)

@@ -9,7 +9,7 @@ import torch
 from torch import Tensor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitk.so")
+LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(_HERE, "libvitk.so")   # VITK_LIB: an experimental build
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_RESIDUAL, EPI_PATCH, EPI_ACT, EPI_GLU, EPI_DACT, EPI_DGLU = 0, 1, 2, 3, 4, 5, 6
@@ -34,6 +34,7 @@ class VitkGemm(C.Structure):
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32), ("algo", C.c_int32),
         ("act", C.c_int32), ("use_limit", C.c_int32), ("use_extra", C.c_int32), ("limit", C.c_float), ("extra_bias", C.c_float),
+        ("a_colsum", C.c_void_p),
     ]
 
 

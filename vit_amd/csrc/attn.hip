@@ -473,6 +473,9 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
 
 template <int DHP, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_fwd_k(AttnP p) {
+#ifdef EXP_STAMP   // diagnostic build: cycle stamps of wave 0 per block go to the lse buffer (tools/stamp_attn.py reads them)
+  const uint64_t st0 = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int KS = Strides<DHP>::ROWS, VS = Strides<DHP>::COLS, TILE = 64 * KS + 64 * VS;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE];   // double buffer: one barrier per key tile
@@ -486,11 +489,17 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_fwd_k(AttnP
 
   const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.q_ss, S, Dh, tid);
   const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.q_ss, S, Dh, tid);
-  uint4 rk[NCH], rv[NCH];
-  stage_load(rk, ksrc, 0);
-  stage_load(rv, vsrc, 0);
+  // two register sets: tile t+2 is requested while tile t is multiplied, so a load has two tile periods to arrive
+  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  // The stationary fragments are requested before the first tile: loads return in order, so the wait that precedes
+  // staging tile 0 also retires them, and nothing inside the loop waits on a load the loop itself has just issued.
   bf16x8 qf[DHP / 16];
   load_stationary<DHP>(qf, qp, p.q_ss, qrow, S, Dh, lane);
+  uint4 rkA[NCH], rvA[NCH], rkB[NCH], rvB[NCH];
+  stage_load(rkA, ksrc, 0);
+  stage_load(rvA, vsrc, 0);
+  stage_load(rkB, ksrc, 1);   // tiles beyond the sequence read as zeros, so prefetches need no condition
+  stage_load(rvB, vsrc, 1);
   const f32x16 zero = ZERO16;
   f32x16 oacc[DHP / 32], lacc = zero;
 #pragma unroll
@@ -498,38 +507,57 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_fwd_k(AttnP
   float m = -INFINITY;
   const float c = p.scale * LOG2E;
   const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.S;
-  stage_store<DHP, NT, NCH, KS, false>(rk, smem, tid);
-  stage_store<DHP, NT, NCH, VS, false>(rv, smem + 64 * KS, tid);
+  stage_store<DHP, NT, NCH, KS, false>(rkA, smem, tid);
+  stage_store<DHP, NT, NCH, VS, false>(rvA, smem + 64 * KS, tid);
   __syncthreads();
+#ifdef EXP_STAMP
+  const uint64_t st1 = __builtin_amdgcn_s_memtime();
+#endif
 
-  // full 64-key tiles, then the tail tile (staged by the last iteration, or before the loop when S < 64)
-  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
-  for (int t = 0; t < nfull; t++) {
+  // full 64-key tiles, then the tail tile (staged by the last step, or above when S < 64).
+  // step(t): nk/nv hold tile t+1, fk/fv are free for tile t+2.
+  auto step = [&](int t, uint4 (&nk)[NCH], uint4 (&nv)[NCH], uint4 (&fk)[NCH], uint4 (&fv)[NCH]) {
     const char* sK = smem + (t & 1) * TILE;
     const char* sV = sK + 64 * KS;
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      stage_load(rk, ksrc, t + 1);
-      stage_load(rv, vsrc, t + 1);
-    }
+    stage_load(fk, ksrc, t + 2);   // unconditional: a conditional load would make every later wait a full drain
+    stage_load(fv, vsrc, t + 2);
     if (wave_on) fwd_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, t * 64, S, rbase, lane);
-    if (more) {
-      char* nK = smem + ((t + 1) & 1) * TILE;
-      stage_store<DHP, NT, NCH, KS, false>(rk, nK, tid);
-      stage_store<DHP, NT, NCH, VS, false>(rv, nK + 64 * KS, tid);
-    }
+    char* nK = smem + ((t + 1) & 1) * TILE;
+    stage_store<DHP, NT, NCH, KS, false>(nk, nK, tid);
+    stage_store<DHP, NT, NCH, VS, false>(nv, nK + 64 * KS, tid);
     __syncthreads();
+  };
+  for (int t = 0; t < nfull; t += 2) {
+    step(t, rkB, rvB, rkA, rvA);
+    if (t + 1 < nfull) step(t + 1, rkA, rvA, rkB, rvB);
   }
+#ifdef EXP_STAMP
+  const uint64_t st2 = __builtin_amdgcn_s_memtime();
+#endif
   if (nfull < ntiles && wave_on) {
     const char* sK = smem + (nfull & 1) * TILE;
     const char* sV = sK + 64 * KS;
     if (S - nfull * 64 > 32) fwd_tile<DHP, 2, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, S, rbase, lane);
     else fwd_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, S, rbase, lane);
   }
+#ifdef EXP_STAMP
+  const uint64_t st3 = __builtin_amdgcn_s_memtime();
+#endif
   if (qrow >= S) return;
   const float l = lacc[0];
   store_rows<DHP>((bf16*)p.o + b * p.o_sb + h * p.o_sh + (int64_t)qrow * p.o_ss, oacc, 1.f / l, Dh, lane);
+#ifndef EXP_STAMP
   if (lane < 32) p.lse[(b * p.H + h) * p.S + qrow] = m * p.scale + __logf(l);
+#else
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint64_t st4 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) {
+    uint32_t* dbg = (uint32_t*)p.lse + (((int64_t)blockIdx.z * p.H + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+    dbg[0] = (uint32_t)st0; dbg[1] = (uint32_t)(st0 >> 32); dbg[2] = (uint32_t)(st1 - st0); dbg[3] = (uint32_t)(st2 - st1);
+    dbg[4] = (uint32_t)(st3 - st2); dbg[5] = (uint32_t)(st4 - st3);
+    dbg[6] = __builtin_amdgcn_s_getreg(63492); dbg[7] = __builtin_amdgcn_s_getreg(6164);
+  }
+#endif
 }
 
 // ---- backward: dQ -------------------------------------------------------------------------------
@@ -586,20 +614,23 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_dq_k(AttnP 
 
   const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.q_ss, S, Dh, tid);
   const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.q_ss, S, Dh, tid);
-  uint4 rk[NCH], rv[NCH];
-  stage_load(rk, ksrc, 0);
-  stage_load(rv, vsrc, 0);
-  bf16x8 qf[DHP / 16], gf[DHP / 16];
+  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  // stationary operands first (see attn_fwd_k)
+  bf16x8 qf[DHP / 16], gf[DHP / 16], of[DHP / 16];
   load_stationary<DHP>(qf, qp, p.q_ss, qrow, S, Dh, lane);
   load_stationary<DHP>(gf, gp, p.o_ss, qrow, S, Dh, lane);
+  load_stationary<DHP>(of, (const bf16*)p.o + b * p.o_sb + h * p.o_sh, p.o_ss, qrow, S, Dh, lane);
   const int64_t srow = (b * p.H + h) * p.S + qrow;
   const float nlse2 = qv ? -p.lse[srow] * LOG2E : 0.f;
+  uint4 rkA[NCH], rvA[NCH], rkB[NCH], rvB[NCH];
+  stage_load(rkA, ksrc, 0);
+  stage_load(rvA, vsrc, 0);
+  stage_load(rkB, ksrc, 1);   // tiles beyond the sequence read as zeros, so prefetches need no condition
+  stage_load(rvB, vsrc, 1);
   // delta = rowsum(dO * O), computed here (each half-wave holds half of the row) and published for attn_dkdv_k,
   // which is launched after this kernel on the same stream
   float delta = 0.f;
   {
-    bf16x8 of[DHP / 16];
-    load_stationary<DHP>(of, (const bf16*)p.o + b * p.o_sb + h * p.o_sh, p.o_ss, qrow, S, Dh, lane);
 #pragma unroll
     for (int ks = 0; ks < DHP / 16; ks++)
 #pragma unroll
@@ -613,26 +644,24 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_dq_k(AttnP 
   f32x16 dqacc[DHP / 32];
 #pragma unroll
   for (int dt = 0; dt < DHP / 32; dt++) dqacc[dt] = zero;
-  stage_store<DHP, NT, NCH, KS, true>(rk, smem, tid);
-  stage_store<DHP, NT, NCH, VS, false>(rv, smem + 64 * KS, tid);
+  stage_store<DHP, NT, NCH, KS, true>(rkA, smem, tid);
+  stage_store<DHP, NT, NCH, VS, false>(rvA, smem + 64 * KS, tid);
   __syncthreads();
 
-  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
-  for (int t = 0; t < nfull; t++) {
+  auto step = [&](int t, uint4 (&nk)[NCH], uint4 (&nv)[NCH], uint4 (&fk)[NCH], uint4 (&fv)[NCH]) {
     const char* sK = smem + (t & 1) * TILE;
     const char* sV = sK + 64 * KS;
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      stage_load(rk, ksrc, t + 1);
-      stage_load(rv, vsrc, t + 1);
-    }
+    stage_load(fk, ksrc, t + 2);   // unconditional: a conditional load would make every later wait a full drain
+    stage_load(fv, vsrc, t + 2);
     if (wave_on) dq_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, t * 64, S, rbase, lane);
-    if (more) {
-      char* nK = smem + ((t + 1) & 1) * TILE;
-      stage_store<DHP, NT, NCH, KS, true>(rk, nK, tid);
-      stage_store<DHP, NT, NCH, VS, false>(rv, nK + 64 * KS, tid);
-    }
+    char* nK = smem + ((t + 1) & 1) * TILE;
+    stage_store<DHP, NT, NCH, KS, true>(nk, nK, tid);
+    stage_store<DHP, NT, NCH, VS, false>(nv, nK + 64 * KS, tid);
     __syncthreads();
+  };
+  for (int t = 0; t < nfull; t += 2) {
+    step(t, rkB, rvB, rkA, rvA);
+    if (t + 1 < nfull) step(t + 1, rkA, rvA, rkB, rvB);
   }
   if (nfull < ntiles && wave_on) {
     const char* sK = smem + (nfull & 1) * TILE;
@@ -713,50 +742,55 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_
 
   const TileSrc<NCH> qsrc = make_tilesrc<DHP, NT, NCH>(qp, p.q_ss, S, Dh, tid);
   const TileSrc<NCH> gsrc = make_tilesrc<DHP, NT, NCH>(gp, p.o_ss, S, Dh, tid);
-  uint4 rq[NCH], rg[NCH];
-  float rl = 0.f;
-  // rows beyond S: -lse = -inf makes their probability exactly 0
-  auto load_row_consts = [&](int q0) {
-    if (tid < 128) {
-      const int qq = q0 + (tid & 63);
-      rl = qq < S ? (tid < 64 ? -p.lse[sbase + qq] * LOG2E : p.delta[sbase + qq]) : (tid < 64 ? -INFINITY : 0.f);
-    }
+  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  uint4 rqA[NCH], rgA[NCH], rqB[NCH], rgB[NCH];
+  float rlA = 0.f, rlB = 0.f;
+  // per-row constants of a query tile: wave 0 fetches -lse*log2e, wave 1 delta (branch-free buffer loads).
+  // Rows beyond S get -lse = -inf, which makes their probability exactly 0.
+  const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + sbase), 0, (int)(S * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.delta + sbase), 0, (int)(S * 4), 0x00020000);
+  auto load_row_consts = [&](float& rl, int q0) {
+    const int qq = q0 + (tid & 63);
+    const uint32_t off = wid < 2 ? (uint32_t)qq * 4u : OOB_OFF;   // wid is wave-uniform: scalar descriptor select
+    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wid == 0 ? lrs : drs, off, 0, 0));
+    rl = wid == 0 ? (qq < S ? -v * LOG2E : -INFINITY) : v;
   };
-  stage_load(rq, qsrc, 0);
-  stage_load(rg, gsrc, 0);
-  load_row_consts(0);
-  bf16x8 kf[DHP / 16], vf[DHP / 16];
+  bf16x8 kf[DHP / 16], vf[DHP / 16];   // stationary operands first (see attn_fwd_k)
   load_stationary<DHP>(kf, kp, p.q_ss, krow, S, Dh, lane);
   load_stationary<DHP>(vf, vp, p.q_ss, krow, S, Dh, lane);
+  stage_load(rqA, qsrc, 0);
+  stage_load(rgA, gsrc, 0);
+  load_row_consts(rlA, 0);
+  stage_load(rqB, qsrc, 1);
+  stage_load(rgB, gsrc, 1);
+  load_row_consts(rlB, 64);
   const float c = p.scale * LOG2E;
   const f32x16 zero = ZERO16;
   f32x16 dkacc[DHP / 32], dvacc[DHP / 32];
 #pragma unroll
   for (int dt = 0; dt < DHP / 32; dt++) { dkacc[dt] = zero; dvacc[dt] = zero; }
-  stage_store<DHP, NT, NCH, QS, true>(rq, smem, tid);
-  stage_store<DHP, NT, NCH, QS, true>(rg, smem + 64 * QS, tid);
-  if (tid < 128) ((float*)(smem + 2 * 64 * QS))[tid] = rl;
+  stage_store<DHP, NT, NCH, QS, true>(rqA, smem, tid);
+  stage_store<DHP, NT, NCH, QS, true>(rgA, smem + 64 * QS, tid);
+  if (tid < 128) ((float*)(smem + 2 * 64 * QS))[tid] = rlA;
   __syncthreads();
 
-  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
-  for (int t = 0; t < nfull; t++) {
+  auto step = [&](int t, uint4 (&nq)[NCH], uint4 (&ng)[NCH], float& nl, uint4 (&fq)[NCH], uint4 (&fg)[NCH], float& fl) {
     const char* sQ = smem + (t & 1) * TILE;
     const char* sG = sQ + 64 * QS;
     const float* sL = (const float*)(sQ + 2 * 64 * QS);
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      stage_load(rq, qsrc, t + 1);
-      stage_load(rg, gsrc, t + 1);
-      load_row_consts((t + 1) * 64);
-    }
+    stage_load(fq, qsrc, t + 2);
+    stage_load(fg, gsrc, t + 2);
+    load_row_consts(fl, (t + 2) * 64);
     if (wave_on) dkdv_tile<DHP, 2, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, t * 64, sbase, krow, lane);
-    if (more) {
-      char* nQ = smem + ((t + 1) & 1) * TILE;
-      stage_store<DHP, NT, NCH, QS, true>(rq, nQ, tid);
-      stage_store<DHP, NT, NCH, QS, true>(rg, nQ + 64 * QS, tid);
-      if (tid < 128) ((float*)(nQ + 2 * 64 * QS))[tid] = rl;
-    }
+    char* nQ = smem + ((t + 1) & 1) * TILE;
+    stage_store<DHP, NT, NCH, QS, true>(nq, nQ, tid);
+    stage_store<DHP, NT, NCH, QS, true>(ng, nQ + 64 * QS, tid);
+    if (tid < 128) ((float*)(nQ + 2 * 64 * QS))[tid] = nl;
     __syncthreads();
+  };
+  for (int t = 0; t < nfull; t += 2) {
+    step(t, rqB, rgB, rlB, rqA, rgA, rlA);
+    if (t + 1 < nfull) step(t + 1, rqA, rgA, rlA, rqB, rgB, rlB);
   }
   if (nfull < ntiles && wave_on) {
     const char* sQ = smem + (nfull & 1) * TILE;

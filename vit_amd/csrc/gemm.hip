@@ -25,7 +25,40 @@ struct Epi {
   uint32_t thr;
   int act, use_limit, use_extra;
   float limit, extra;
+  void* asum;            // A^T-layout products: asum[m] = sum over k of A[k, m] (dtype of out), or NULL
+  float* asum_partial;   // split-K: per-split partial sums [splits][M]
 };
+
+// sum of a fragment's 8 bf16 values added to s (4 x v_dot2c_f32_bf16 against ones)
+__device__ __forceinline__ float frag_sum(const bf16x8& f, float s) {
+  typedef __attribute__((ext_vector_type(2))) bf16 bf16x2_t;
+  bf16x2_t ones;
+  ones[0] = (bf16)1.f;
+  ones[1] = (bf16)1.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    bf16x2_t t;
+    t[0] = f[2 * j];
+    t[1] = f[2 * j + 1];
+    s = __builtin_amdgcn_fdot2_f32_bf16(t, ones, s, false);
+  }
+  return s;
+}
+// rows of the A operand summed over the block's K range, written by the waves that own the block's first column slice:
+// lane l and l+32 hold the two k-halves of row (l & 31) of each 32-row group
+template <int NI, int MODE, class TO>
+__device__ __forceinline__ void asum_store(const Epi& e, const float (&rs)[NI], int64_t mrow0, int64_t M, int64_t split, int lane) {
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const float s = rs[i] + __shfl_xor(rs[i], 32, 64);
+    const int64_t m = mrow0 + i * 32 + (lane & 31);
+    if (lane < 32 && m < M) {
+      if (MODE == -1) e.asum_partial[split * M + m] = s;
+      else ((TO*)e.asum)[m] = from_f<TO>(s);
+    }
+  }
+}
+
 
 constexpr int EPI_ACT = VITK_EPI_ACT, EPI_GLU = VITK_EPI_GLU, EPI_DACT = VITK_EPI_DACT, EPI_DGLU = VITK_EPI_DGLU;
 
@@ -518,11 +551,13 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE_B];
   char* sA = smem;
   char* sB = smem + TILE_B;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
   const int64_t m0 = tm * BM, n0 = tn * BN;
+  const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
+  float rs[2] = {0.f, 0.f};
   const int64_t kbeg = split * klen;
   const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
 
@@ -549,6 +584,10 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (TA && asum_on) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) rs[i] = frag_sum(af[i], rs[i]);
+      }
     }
   };
   uint4 ra[4], rb[4];
@@ -574,6 +613,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A
   multiply();
   __syncthreads();
 
+  if (TA && asum_on) asum_store<2, MODE, TO>(e, rs, m0 + wm * 64, M, split, lane);
   float* stg = (float*)smem + wid * (32 * STG_LD);
 #pragma unroll
   for (int i = 0; i < 2; i++) {
@@ -609,12 +649,14 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
                                                       int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
                                                       int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE2_B];   // [buffer][A|B]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;            // waves w and w+4 share a SIMD; grp 1 runs one interval behind grp 0
   const int wm = grp, wn = wid & 3;    // wave tile: rows [wm*128, +128), columns [wn*64, +64)
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
   const int64_t m0 = tm * BM2, n0 = tn * BN2;
+  const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t kbeg = split * klen;
   const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
   const int32_t klen_here = (int32_t)(kend - kbeg);
@@ -669,6 +711,12 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    if (TA && asum_on) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs[i] = frag_sum(af[ks][i], rs[i]);
+    }
     __builtin_amdgcn_s_setprio(0);
     phase_barrier();
     // ---- R2: fragments of k-substeps 2,3; stage B of tile k+1; fetch B of tile k+2
@@ -692,6 +740,12 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    if (TA && asum_on) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs[i] = frag_sum(af[ks][i], rs[i]);
+    }
     __builtin_amdgcn_s_setprio(0);
     phase_barrier();
   }
@@ -700,6 +754,7 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
 
   EpiCols<MODE, TO> cols;
   cols.init(e, n0 + wn * 64, N, lane);
+  if (TA && asum_on) asum_store<4, MODE, TO>(e, rs, m0 + wm * 128, M, split, lane);
   float* stg = (float*)smem + wid * (32 * STG_LD);
   SlabPre<MODE, TO> pre;
 #pragma unroll
@@ -719,6 +774,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
     float s = 0.f;
     for (int k = 0; k < splits; k++) s += partial[(int64_t)k * total + i];
     EpiOp<MODE, TI, TO>::apply(e, i / N, i % N, s);
+  }
+  if (e.asum) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+      float s = 0.f;
+      for (int k = 0; k < splits; k++) s += e.asum_partial[(int64_t)k * M + i];
+      ((TO*)e.asum)[i] = from_f<TO>(s);
+    }
   }
 }
 
@@ -771,9 +833,10 @@ static int pick_splits(const VitkGemm* g) {
 }
 
 extern "C" size_t vitk_gemm_workspace_bytes(const VitkGemm* g) {
-  if (!g || !mfma_ok(g) || g->algo == 1) return 0;
+  if (!g) return 0;
+  if (!mfma_ok(g) || g->algo == 1) return g->a_colsum ? vitk_colsum_workspace_bytes(g->M) : 0;   // separate column-sum pass
   const int s = pick_splits(g);
-  return s > 1 ? (size_t)s * (size_t)g->M * (size_t)g->N * sizeof(float) : 0;
+  return s > 1 ? (size_t)s * (size_t)g->M * ((size_t)g->N + (g->a_colsum ? 1 : 0)) * sizeof(float) : 0;
 }
 
 static Epi make_epi(const VitkGemm* g) {
@@ -784,6 +847,7 @@ static Epi make_epi(const VitkGemm* g) {
   e.thr = g->drop_p > 0.f ? drop_threshold(g->drop_p) : 0;
   e.keep_scale = 1.f / (1.f - g->drop_p);
   e.act = g->act; e.use_limit = g->use_limit; e.use_extra = g->use_extra; e.limit = g->limit; e.extra = g->extra_bias;
+  e.asum = g->a_colsum; e.asum_partial = nullptr;
   return e;
 }
 
@@ -828,12 +892,14 @@ static void launch_mfma_one(const VitkGemm* g, const Epi& e, int splits, int64_t
 template <bool TA, bool TB, class TO>
 static void launch_mfma_layout(const VitkGemm* g, const Epi& e, int splits, int64_t klen, hipStream_t st) {
   if (splits > 1) {
-    launch_mfma_one<TA, TB, MODE_PARTIAL, TO>(g, e, splits, klen, (float*)g->workspace, st);
+    Epi ep = e;
+    ep.asum_partial = (float*)g->workspace + (size_t)splits * g->M * g->N;
+    launch_mfma_one<TA, TB, MODE_PARTIAL, TO>(g, ep, splits, klen, (float*)g->workspace, st);
     const int64_t total = g->M * g->N;
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((splitk_reduce_k<VITK_EPI_STORE, bf16, TO>), dim3((unsigned)blocks), dim3(256), 0, st,
-                       (const float*)g->workspace, g->M, g->N, splits, e);
+                       (const float*)g->workspace, g->M, g->N, splits, ep);
   } else {
     launch_mfma_one<TA, TB, VITK_EPI_STORE, TO>(g, e, 1, klen, nullptr, st);
   }
@@ -842,7 +908,8 @@ static void launch_mfma_layout(const VitkGemm* g, const Epi& e, int splits, int6
 template <class TO>
 static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st) {
   int splits = pick_splits(g);
-  if (splits > 1 && (!g->workspace || (size_t)g->workspace_bytes < (size_t)splits * g->M * g->N * sizeof(float))) splits = 1;
+  if (splits > 1 && (!g->workspace || (size_t)g->workspace_bytes < (size_t)splits * g->M * (g->N + (g->a_colsum ? 1 : 0)) * sizeof(float)))
+    splits = 1;
   int64_t klen = ceil_div(ceil_div(g->K, splits), BK) * BK;
   splits = (int)ceil_div(g->K, klen);
   if (g->epilogue == VITK_EPI_RESIDUAL) launch_mfma_one<false, false, VITK_EPI_RESIDUAL, TO>(g, e, 1, klen, nullptr, st);
@@ -876,6 +943,7 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   if (g->epilogue == VITK_EPI_PATCH)
     VITK_REQUIRE(g->tokens > 0 && g->M % g->tokens == 0 && g->seq >= g->prefix + g->tokens,
                  "gemm: PATCH epilogue needs tokens | M and seq >= prefix + tokens");
+  if (g->a_colsum) VITK_REQUIRE(g->trans_a && g->epilogue == VITK_EPI_STORE, "gemm: a_colsum needs trans_a = 1 and the STORE epilogue");
   if (g->M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const Epi e = make_epi(g);
@@ -890,6 +958,12 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
     if (g->in_dtype == VITK_F32) launch_simple<float, float>(g, e, st);
     else if (g->out_dtype == VITK_F32) launch_simple<bf16, float>(g, e, st);
     else launch_simple<bf16, bf16>(g, e, st);
+    if (g->a_colsum) {   // the portable kernel has no fused row sums: one pass over A ([K, M], column sums)
+      VITK_REQUIRE(g->workspace && (size_t)g->workspace_bytes >= vitk_colsum_workspace_bytes(g->M), "gemm: a_colsum needs the workspace");
+      if (int rc = vitk_colsum(g->a, g->in_dtype, g->lda, nullptr, nullptr, 0, 0, g->a_colsum, g->out_dtype, g->K, g->M, 1.f,
+                               g->workspace, stream))
+        return rc;
+    }
   }
   VITK_LAUNCH_CHECK("gemm");
   return 0;

@@ -95,9 +95,11 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
          gamma: Optional[Tensor] = None, row_idx: Optional[Tensor] = None, aux: Optional[Tensor] = None,
          pos: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
          tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None,
-         tag: str = "", act: int = 0, limit: Optional[float] = None, extra: Optional[float] = None) -> Tensor:
+         tag: str = "", act: int = 0, limit: Optional[float] = None, extra: Optional[float] = None,
+         a_colsum: Optional[Tensor] = None) -> Tensor:
+    """``a_colsum`` ([M], dtype of out; trans_a products only) receives sum_k A[k, m] from the same pass."""
     lib = L.load()
-    L.require_gpu(a, b, out, bias, res, gamma, aux, pos)
+    L.require_gpu(a, b, out, bias, res, gamma, aux, pos, a_colsum)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1, "gemm operands must be row-major 2-D"
     assert a.dtype == b.dtype
     for t in (bias, aux, pos):
@@ -109,6 +111,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     g.a, g.b, g.out = L.ptr(a), L.ptr(b), L.ptr(out)
     g.bias, g.res, g.gamma, g.row_idx, g.aux, g.pos = (L.ptr(bias), L.ptr(res), L.ptr(gamma), L.ptr(row_idx), L.ptr(aux),
                                                        L.ptr(pos))
+    assert a_colsum is None or (a_colsum.dtype == out.dtype and a_colsum.is_contiguous() and a_colsum.numel() == M)
+    g.a_colsum = L.ptr(a_colsum)
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb = a.stride(0), b.stride(0)
     g.ldo = out.shape[-1] if ldo is None else ldo

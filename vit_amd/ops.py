@@ -74,8 +74,10 @@ def _linear_bwd(dy: Tensor, inp: Tensor, w_c: Tensor, need_dx: bool, need_dw: bo
         K.gemm(dy, w_c, trans_a=False, trans_b=True, M=M, N=Kin, K=N, out=dx, tag=tag + ".dgrad")
     if need_dw:
         dw = torch.empty((N, Kin), dtype=wdtype, device=dy.device)
-        K.gemm(dy, inp, trans_a=True, trans_b=True, M=N, N=Kin, K=M, out=dw, tag=tag + ".wgrad")
-    if need_db:
+        if need_db:  # the bias gradient dy.sum(0) comes out of the weight-gradient pass over dy
+            db = torch.empty((N,), dtype=wdtype, device=dy.device)
+        K.gemm(dy, inp, trans_a=True, trans_b=True, M=N, N=Kin, K=M, out=dw, a_colsum=db, tag=tag + ".wgrad")
+    elif need_db:
         db = K.colsum(dy, M, N, N, wdtype)
     return dx, dw, db
 

@@ -61,7 +61,8 @@ int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, cons
  *                     out[row(m),n] = res[row(m),n] + alpha * gamma[n] * t      (gamma optional)
  *   VITK_EPI_PATCH    out[(m / tokens) * seq + prefix + m % tokens, n] = acc + bias[n] + pos[m % tokens, n]
  * algo: 0 = auto, 1 = portable scalar kernel (any dtype/shape), 2 = bf16 MFMA kernel (rejects what it cannot do),
- *       3 / 4 = MFMA kernel with the 256x256 / 128x128 tile forced (tuning and tests).
+ *       3 / 4 / 5 = MFMA kernel forced to the 256x256 tile with register staging / the 128x128 tile / the 256x256 tile
+ *       with LDS-DMA staging (tuning and tests; 0 picks between the last two).
  * split-K (wgrad) partials live in `workspace` (vitk_gemm_workspace_bytes). */
 enum {
   VITK_EPI_STORE = 0, VITK_EPI_RESIDUAL = 1, VITK_EPI_PATCH = 2,

@@ -44,7 +44,7 @@ def test_mfma_gemm_exact_on_integers(layout, shape):
     out = torch.empty(M, N, device=DEV, dtype=torch.float32)
     K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out, algo=2)
     assert torch.equal(out, ref), f"max err {(out - ref).abs().max().item()}"
-    for algo in (1, 3, 4):  # portable, 256x256-tile MFMA, 128x128-tile MFMA
+    for algo in (1, 3, 4, 5):  # portable, 256x256-tile MFMA, 128x128-tile MFMA, 256x256 tile with LDS-DMA staging
         out1 = torch.empty_like(out)
         K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out1, algo=algo)
         assert torch.equal(out1, ref), f"algo {algo}: max err {(out1 - ref).abs().max().item()}"
@@ -61,7 +61,7 @@ def test_gemm_fused_bias_gradient_row_sums(shape):
     ref, ref_sum = (A.t() @ B).to(DEV), A.sum(0).to(DEV)
     a, b = A.to(DEV, torch.bfloat16), B.to(DEV, torch.bfloat16)
     for od in (torch.float32, torch.bfloat16):
-        for algo in (0, 1, 3, 4):
+        for algo in (0, 1, 3, 4, 5):
             out = torch.empty(M, N, device=DEV, dtype=od)
             sums = torch.full((M,), float("nan"), device=DEV, dtype=od)
             K.gemm(a, b, trans_a=True, trans_b=True, M=M, N=N, K=Kd, out=out, a_colsum=sums, algo=algo)

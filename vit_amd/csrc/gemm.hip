@@ -766,6 +766,226 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256x256x64 kernel with LDS-DMA staging and 16x16x32 MFMAs.  Same wave layout (8 waves, 128x64 each), phases and
+// stagger as gemm_mfma256_k, but operand tiles go from global memory straight into LDS (buffer_load ... lds): no
+// staging registers and no ds_write traffic.  The 16x16x32 shape does the same work per cycle as 32x32x16 at lower
+// power, which is what bounds this kernel (the chip holds ~1.6 GHz under it).
+// LDS is a ring of 4 slots, one per half K-step (32 k = one MFMA k-step): [A 16 KiB][B 16 KiB].  A DMA instruction
+// fills 1 KiB in lane order, so rows cannot be padded; bank conflicts are avoided by storing each unit at a permuted
+// position and applying the same permutation to the SOURCE address:
+//   K-contiguous operand  [256 rows][4 x 16 B]:  unit c of row r at position c ^ G[(r >> 2) & 3],  G = {0, 2, 3, 1}
+//   contraction-major     [32 k][16 x 32 B]:     32-byte unit u of k-row k at position u ^ ((k & 3) | ((k >> 3) & 1) << 2)
+// (each ds_read_b128 lane group then meets 16 distinct bank quads; each 32-lane half of a transposing read meets 8
+// distinct 32-byte bank octants).
+// Schedule per K-step k (each wave group; group 1 runs one barrier behind group 0):
+//   R0: fragments of half-stage 2k, request half-stage 2k+3 | M1: 32 MFMA | R2: fragments of 2k+1, request 2k+4 | M3.
+// A half-stage is requested 6 barrier intervals before its first read.  Every wave issues 4 DMA instructions per
+// request, so "all but the 8 youngest complete" before each barrier retires exactly the half-stage read next, for
+// both groups; fragment reads are drained before the barrier that ends their phase, so a slot is never refilled
+// under a pending read.
+// ------------------------------------------------------------------------------------------------
+constexpr int HS_B = 16384;        // one operand's half-stage
+constexpr int SLOT_B = 2 * HS_B;   // A then B
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ int swz_rows(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }            // G[(r>>2)&3]
+__device__ __forceinline__ int swz_krow(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+struct DmaSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[2];   // this lane's two 16-byte units at half-stage 0 (byte offsets), or OOB
+  int32_t klim[2];    // K-contiguous operand: unit valid while kk < klim
+  uint32_t hstride;   // bytes per half-stage
+};
+
+template <bool TR, bool GLUMAP>
+__device__ __forceinline__ DmaSrc make_dma(const bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t nrows, int64_t kbeg,
+                                           int64_t kend, int64_t Ktot, int wid, int lane) {
+  DmaSrc t;
+  if (!TR) {
+    const int64_t base_row = GLUMAP ? 0 : row0;
+    const int64_t span_rows = GLUMAP ? nrows : (nrows - row0 < 256 ? nrows - row0 : 256);
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + base_row * ld), 0, clip32(((span_rows - 1) * ld + Ktot) * 2), 0x00020000);
+    t.hstride = 64;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int p = (wid * 2 + j) * 64 + lane;
+      const int row = p >> 2, c = (p & 3) ^ swz_rows(row);
+      const int64_t r = row0 + row;
+      const int64_t rr = GLUMAP ? glu_row(r, nrows >> 1) : (int64_t)row;
+      t.voff[j] = r < nrows ? (uint32_t)((rr * ld + kbeg + c * 8) * 2) : OOB;
+      t.klim[j] = (int32_t)(kend - kbeg) - c * 8;
+    }
+  } else {
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + kbeg * ld + row0), 0,
+                                               clip32(((kend - kbeg - 1) * ld + (nrows - row0)) * 2), 0x00020000);
+    t.hstride = (uint32_t)(32 * ld * 2);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int p = (wid * 2 + j) * 64 + lane;
+      const int krow = p >> 5, col = ((p & 31) ^ (swz_krow(krow) << 1)) * 8;
+      t.voff[j] = row0 + col < nrows ? (uint32_t)(((int64_t)krow * ld + col) * 2) : OOB;
+      t.klim[j] = 0x7fffffff;
+    }
+  }
+  return t;
+}
+
+// request half-stage h (k offset 32*h from the block's first k) of one operand into `dst`
+template <bool TR>
+__device__ __forceinline__ void dma_half(const DmaSrc& t, char* dst, int wid, int h) {
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    uint32_t off = t.voff[j] + (uint32_t)h * t.hstride;
+    if (!TR) off = (h * 32 < t.klim[j] && t.voff[j] != OOB) ? off : OOB;
+    else off = t.voff[j] != OOB ? off : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rsrc, (lds_void_t*)(dst + (wid * 2 + j) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+// 16x16x32 operand fragment from a DMA-staged half-stage: index r0 + (lane & 15) (r0 a multiple of 16),
+// k = 8*(lane>>4) + j
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag16(const char* hs, int r0, int lane) {
+  if (!TR) {
+    const int row = r0 + (lane & 15);
+    return *(const bf16x8*)(hs + row * 64 + (((lane >> 4) ^ swz_rows(row)) << 4));
+  } else {
+    const int i = lane & 15;
+    const int krow = 8 * (lane >> 4) + (i >> 2);
+    const char* p = hs + krow * 512 + ((((r0 >> 4) ^ swz_krow(krow))) << 5) + 8 * (i & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * 512));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+}
+
+// barrier that leaves DMA requests in flight: only the half-stage read next has to be complete
+__device__ __forceinline__ void dma_barrier(bool drain_reads) {
+  __builtin_amdgcn_sched_barrier(0);
+  if (drain_reads) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// 32-row x 64-column slab (row tiles 2s, 2s+1 of a wave's 8 x 4 grid of 16x16 accumulators) -> the wave's LDS slab.
+// Accumulator register r of lane l is row 4*(l>>4) + r, column l&15 of its tile.
+__device__ __forceinline__ void slab_stage16(float* stg, const f32x4_t (&acc)[8][4], int s, int lane) {
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        stg[(16 * h + 4 * (lane >> 4) + r) * STG_LD + 16 * j + (lane & 15)] = acc[2 * s + h][j][r];
+}
+
+template <bool TA, bool TB, int MODE, class TO>
+__global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ A, const bf16* __restrict__ B, int64_t M,
+                                                       int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
+                                                       int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(1024))) char smem[4 * SLOT_B];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;
+  const int wm = grp, wn = wid & 3;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  const int64_t m0 = tm * BM2, n0 = tn * BN2;
+  const int64_t kbeg = split * klen;
+  const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
+  const int32_t klen_here = (int32_t)(kend - kbeg);
+  const int nk = (klen_here + BK - 1) / BK;
+  const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
+  float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
+
+  const DmaSrc sa = make_dma<TA, false>(A, lda, m0, M, kbeg, kend, K, wid, lane);
+  const DmaSrc sb = make_dma<TB, MODE == EPI_GLU>(B, ldb, n0, N, kbeg, kend, K, wid, lane);
+  auto request = [&](int h) {   // unconditional: half-stages past the K range read zeros and are never consumed
+    char* slot = smem + (h & 3) * SLOT_B;
+    dma_half<TA>(sa, slot, wid, h);
+    dma_half<TB>(sb, slot + HS_B, wid, h);
+  };
+  bf16x8 af[8], bfr[4];
+  auto read_frags = [&](const char* slot) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) bfr[j] = read_frag16<TB>(slot + HS_B, wn * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 8; i++) af[i] = read_frag16<TA>(slot, wm * 128 + i * 16, lane);
+  };
+  auto multiply = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (TA && asum_on) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) rs[i] = frag_sum(af[i], rs[i]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  request(0);
+  request(1);
+  request(2);
+  dma_barrier(false);   // half-stage 0 complete
+  if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+  for (int k = 0; k < nk; k++) {
+    read_frags(smem + ((2 * k) & 3) * SLOT_B);       // R0
+    request(2 * k + 3);
+    dma_barrier(true);
+    multiply();                                      // M1
+    dma_barrier(false);
+    read_frags(smem + ((2 * k + 1) & 3) * SLOT_B);   // R2
+    request(2 * k + 4);
+    dma_barrier(true);
+    multiply();                                      // M3
+    dma_barrier(false);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (empty) requests still target LDS
+  if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  __syncthreads();
+
+  EpiCols<MODE, TO> cols;
+  cols.init(e, n0 + wn * 64, N, lane);
+  if (TA && asum_on) {   // row sums: lanes l, l^16, l^32, l^48 hold the four k-quarters of row (l & 15) of each 16-row tile
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float v = rs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
+      if (lane < 16 && m < M) {
+        if (MODE == MODE_PARTIAL) e.asum_partial[split * M + m] = v;
+        else ((TO*)e.asum)[m] = from_f<TO>(v);
+      }
+    }
+  }
+  float* stg = (float*)smem + wid * (32 * STG_LD);
+  SlabPre<MODE, TO> pre;
+#pragma unroll
+  for (int sl = 0; sl < 4; sl++) {
+    const int64_t mbase = m0 + wm * 128 + sl * 32;
+    slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
+    slab_stage16(stg, acc, sl, lane);
+    slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
+  }
+}
+
 template <int MODE, class TI, class TO>
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ partial, int64_t M, int64_t N, int splits,
                                                        Epi e) {
@@ -865,9 +1085,10 @@ static void launch_simple(const VitkGemm* g, const Epi& e, hipStream_t st) {
 #undef LS
 }
 
-// algo 3 forces the 256^2 kernel, algo 4 the 128^2 kernel; otherwise large problems take the 256^2 tile
+// algo 3 / 5 force the 256^2 tile (3: register-staged kernel, 5: LDS-DMA kernel, which is also the automatic choice),
+// algo 4 the 128^2 kernel; otherwise large problems take the 256^2 tile
 static bool use_tile256(const VitkGemm* g) {
-  if (g->algo == 3) return true;
+  if (g->algo == 3 || g->algo == 5) return true;
   if (g->algo == 4) return false;
   if (g->epilogue == VITK_EPI_DGLU) return false;   // its epilogue does not fit the register budget beside 128 accumulators
   // measured on MI355X (ViT-B shapes): the 256^2 tile wins once the output is wide or the contraction long;
@@ -879,6 +1100,11 @@ template <bool TA, bool TB, int MODE, class TO>
 static void launch_mfma_one(const VitkGemm* g, const Epi& e, int splits, int64_t klen, float* partial, hipStream_t st) {
   if (use_tile256(g)) {
     const int64_t tm = ceil_div(g->M, BM2), tn = ceil_div(g->N, BN2);
+    if (g->algo != 3) {   // algo 3 keeps the register-staged 32x32x16 kernel for comparisons
+      hipLaunchKernelGGL((gemm_mfma256d_k<TA, TB, MODE, TO>), dim3((unsigned)(tm * tn * splits)), dim3(512), 0, st,
+                         (const bf16*)g->a, (const bf16*)g->b, g->M, g->N, g->K, g->lda, g->ldb, tm, tn, klen, e, partial);
+      return;
+    }
     hipLaunchKernelGGL((gemm_mfma256_k<TA, TB, MODE, TO>), dim3((unsigned)(tm * tn * splits)), dim3(512), 0, st,
                        (const bf16*)g->a, (const bf16*)g->b, g->M, g->N, g->K, g->lda, g->ldb, tm, tn, klen, e, partial);
     return;

@@ -44,7 +44,7 @@ def test_mfma_gemm_exact_on_integers(layout, shape):
     out = torch.empty(M, N, device=DEV, dtype=torch.float32)
     K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out, algo=2)
     assert torch.equal(out, ref), f"max err {(out - ref).abs().max().item()}"
-    for algo in (1, 3, 4, 5):  # portable, 256x256-tile MFMA, 128x128-tile MFMA, 256x256 tile with LDS-DMA staging
+    for algo in (1, 3, 4, 5):  # portable, 256x256-tile MFMA (register staged), 128x128-tile MFMA, 256x256 tile with LDS-DMA staging
         out1 = torch.empty_like(out)
         K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out1, algo=algo)
         assert torch.equal(out1, ref), f"algo {algo}: max err {(out1 - ref).abs().max().item()}"

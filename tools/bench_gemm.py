@@ -80,6 +80,7 @@ for name, layout, m, n, k, epi, odt in cases:
     ms = timeit(fn, 5 if NOREF else 20)
     ms256 = timeit(fn256, 5 if NOREF else 20)
     ms256d = timeit(fn256d, 5 if NOREF else 20)
+
     ms_ref = ms if NOREF else timeit(ref)
     fl = 2.0 * m * n * k
     tot_ms += ms

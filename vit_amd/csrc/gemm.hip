@@ -891,6 +891,9 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
                                                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
                                                        int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial) {
   __shared__ __attribute__((aligned(1024))) char smem[4 * SLOT_B];
+#ifdef EXP_STAMP
+  const uint64_t st0 = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;
   const int wm = grp, wn = wid & 3;
@@ -942,6 +945,9 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   request(1);
   request(2);
   dma_barrier(false);   // half-stage 0 complete
+#ifdef EXP_STAMP
+  const uint64_t st1 = __builtin_amdgcn_s_memtime();
+#endif
   if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 
   for (int k = 0; k < nk; k++) {
@@ -956,6 +962,9 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
     multiply();                                      // M3
     dma_barrier(false);
   }
+#ifdef EXP_STAMP
+  const uint64_t st2 = __builtin_amdgcn_s_memtime();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (empty) requests still target LDS
   if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
   __syncthreads();
@@ -984,6 +993,18 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
     slab_stage16(stg, acc, sl, lane);
     slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
   }
+#ifdef EXP_STAMP   // diagnostic build: per-block cycle stamps overwrite the start of aux (tools/stamp_gemm.py reads them)
+  const uint64_t st3 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint64_t st4 = __builtin_amdgcn_s_memtime();
+  __syncthreads();
+  if (tid == 0 && e.aux) {
+    uint32_t* dbg = (uint32_t*)e.aux + (int64_t)blockIdx.x * 8;
+    dbg[0] = (uint32_t)st0; dbg[1] = (uint32_t)(st0 >> 32); dbg[2] = (uint32_t)(st1 - st0); dbg[3] = (uint32_t)(st2 - st1);
+    dbg[4] = (uint32_t)(st3 - st2); dbg[5] = (uint32_t)(st4 - st3);
+    dbg[6] = __builtin_amdgcn_s_getreg(63492); dbg[7] = __builtin_amdgcn_s_getreg(6164);
+  }
+#endif
 }
 
 template <int MODE, class TI, class TO>

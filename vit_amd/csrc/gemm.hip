@@ -544,6 +544,24 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Tile order inside one split: panels of PANEL_M row tiles, walked column tile by column tile.  The blocks of an XCD
+// run consecutive tile ids, so at any time they share a few B column tiles and one panel of A rows, and each B tile is
+// fetched into that XCD's L2 once per panel instead of once per row tile.
+#ifndef PANEL_M_VALUE
+#define PANEL_M_VALUE 8
+#endif
+constexpr int PANEL_M = PANEL_M_VALUE;
+__device__ __forceinline__ void tile_coords(int64_t wg, int64_t tiles_m, int64_t tiles_n, int64_t& tm, int64_t& tn, int64_t& split) {
+  const int64_t per_split = tiles_m * tiles_n;
+  split = wg / per_split;
+  const int64_t r = wg - split * per_split;
+  const int64_t per_panel = PANEL_M * tiles_n;
+  const int64_t panel = r / per_panel, in_panel = r - panel * per_panel;
+  const int64_t rows_here = tiles_m - panel * PANEL_M < PANEL_M ? tiles_m - panel * PANEL_M : PANEL_M;
+  tm = panel * PANEL_M + in_panel % rows_here;
+  tn = in_panel / rows_here;
+}
+
 template <bool TA, bool TB, int MODE, class TO>
 __global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A, const bf16* __restrict__ B, int64_t M,
                                                    int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
@@ -554,7 +572,8 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  int64_t tm, tn, split;
+  tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
   const int64_t m0 = tm * BM, n0 = tn * BN;
   const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
   float rs[2] = {0.f, 0.f};
@@ -653,7 +672,8 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
   const int grp = wid >> 2;            // waves w and w+4 share a SIMD; grp 1 runs one interval behind grp 0
   const int wm = grp, wn = wid & 3;    // wave tile: rows [wm*128, +128), columns [wn*64, +64)
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  int64_t tm, tn, split;
+  tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
   const int64_t m0 = tm * BM2, n0 = tn * BN2;
   const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -898,7 +918,8 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   const int grp = wid >> 2;
   const int wm = grp, wn = wid & 3;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t tn = wg % tiles_n, tm = (wg / tiles_n) % tiles_m, split = wg / (tiles_n * tiles_m);
+  int64_t tm, tn, split;
+  tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
   const int64_t m0 = tm * BM2, n0 = tn * BN2;
   const int64_t kbeg = split * klen;
   const int64_t kend = kbeg + klen < K ? kbeg + klen : K;

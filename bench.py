@@ -80,6 +80,22 @@ def make_model(w: dict, device):
     return cfg, model.train()
 
 
+def fc1_kernel_name(c: dict) -> str:
+    """The kernel behind the "fc1" tag: the 256x256-tile LDS-DMA GEMM with the activation fused in its epilogue."""
+    epi = "GLU" if c["activation"].endswith("glu") else "ACT"
+    return f"gemm_mfma256d_k<NT,{epi},bf16> (fc1 forward)"
+
+
+def measured_traffic(workload: str, batch: int):
+    """HBM-side bytes per fc1 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate
+    runs, gfx950 correction applied); None for a workload / batch the passes were not taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_fc1_traffic.json")
+    if workload != "vit_b14_224_swiglu_reg16_fourier" or batch != 256 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
+
+
 def cpu_baseline(w: dict, seconds: float = 20.0) -> dict:
     """The oracle (torch-op restatement of the reference's eager path) on the host cores: same configuration and
     mode, batch 8 per step, as many steps as fit in ~`seconds`."""
@@ -192,10 +208,10 @@ def main() -> None:
                        "parallelism": f"dp{world}", "step": "fwd + mean loss + bwd + bucketed grad all-reduce + zero_grad",
                        "fwd_bwd_gflop_per_image": round(3 * fpi / 1e9, 1)},
             "step_mfma_frac": round(imgs / world * 3 * fpi / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_mfma_k<NT,STORE> (fc1 forward)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": fc1_kernel_name(c), "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "launch_ms": round(k_ms, 4), "launches_timed": len(pairs),
-                         "flop_per_launch": k_flop},
+                         "traffic": measured_traffic(args.workload, B), "launch_ms": round(k_ms, 4),
+                         "launches_timed": len(pairs), "flop_per_launch": k_flop},
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w)

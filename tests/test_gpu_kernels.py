@@ -71,6 +71,35 @@ def test_gemm_fused_bias_gradient_row_sums(shape):
         K.gemm(a.t().contiguous(), b, trans_a=False, trans_b=True, M=M, N=N, K=Kd, out=out, a_colsum=sums)
 
 
+def test_gemm_ragged_last_round_is_cut_between_tile_sizes():
+    """270 tiles of 256x256 on 256 CUs: the automatic path runs whole rounds on the 256-tile kernel and the remaining
+    rows on the 128-tile kernel.  Integer operands make every kernel exact, so the cut must be invisible; the
+    residual epilogue is checked with a row gather and dropout (same mask as the uncut launch)."""
+    M, N, Kd = 256 * 90, 768, 192
+    g = torch.Generator().manual_seed(11)
+    A = torch.randint(-2, 3, (M, Kd), generator=g).float()
+    B = torch.randint(-2, 3, (Kd, N), generator=g).float()
+    ref = (A @ B).to(DEV)
+    a = A.to(DEV, torch.bfloat16)
+    for layout, b in (("nt", B.t().contiguous().to(DEV, torch.bfloat16)), ("nn", B.to(DEV, torch.bfloat16))):
+        out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+        K.gemm(a, b, trans_a=False, trans_b=layout == "nn", M=M, N=N, K=Kd, out=out, algo=0)
+        assert torch.equal(out, ref), layout
+    bt = B.t().contiguous().to(DEV, torch.bfloat16)
+    rows = torch.randperm(M + 512, generator=g)[:M].to(DEV)
+    x = torch.randn(M + 512, N, generator=g).to(DEV)
+    outs = []
+    for algo in (0, 4):
+        o = x.clone()
+        aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        K.gemm(a, bt, trans_a=False, trans_b=False, M=M, N=N, K=Kd, out=o, res=o, epilogue=L.EPI_RESIDUAL, row_idx=rows,
+               aux=aux, alpha=0.5, drop_p=0.25, seed=321, algo=algo)
+        outs.append((o, aux))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    kept = (outs[0][1] != 0).float().mean().item()
+    assert 0.6 < kept < 0.8   # ~75% kept (zeros of the product itself excluded by the loose band)
+
+
 def test_mfma_gemm_splitk_wgrad_shape():
     M, N, Kd = 256, 128, 4096  # few output tiles, long contraction -> split-K path
     g = torch.Generator().manual_seed(3)

@@ -80,10 +80,12 @@ for name, layout, m, n, k, epi, odt in cases:
     ms = timeit(fn, 5 if NOREF else 20)
     ms256 = timeit(fn256, 5 if NOREF else 20)
     ms256d = timeit(fn256d, 5 if NOREF else 20)
+    fnauto = lambda: K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=m, N=n, K=k, out=out, algo=0, **kw)
+    msauto = timeit(fnauto, 5 if NOREF else 20)
 
     ms_ref = ms if NOREF else timeit(ref)
     fl = 2.0 * m * n * k
     tot_ms += ms
     tot_fl += fl
-    print(f"{name:10s} {layout} M={m:6d} N={n:5d} K={k:6d}  t128 {ms:6.3f} ms {fl / ms / 1e9:6.1f} TF  t256 {ms256:6.3f} ms {fl / ms256 / 1e9:6.1f} TF  t256dma {ms256d:6.3f} ms {fl / ms256d / 1e9:6.1f} TF  torch.matmul {ms_ref:7.3f} ms {fl / ms_ref / 1e9:7.1f} TF/s", flush=True)
+    print(f"{name:10s} {layout} M={m:6d} N={n:5d} K={k:6d}  t128 {ms:6.3f} ms {fl / ms / 1e9:6.1f} TF  t256 {ms256:6.3f} ms {fl / ms256 / 1e9:6.1f} TF  t256dma {ms256d:6.3f} ms {fl / ms256d / 1e9:6.1f} TF  auto {msauto:6.3f} ms {fl / msauto / 1e9:6.1f} TF  torch.matmul {ms_ref:7.3f} ms {fl / ms_ref / 1e9:7.1f} TF/s", flush=True)
 print(f"sum over one layer: {tot_ms:.3f} ms, {tot_fl / tot_ms / 1e9:.1f} TF/s")

@@ -27,6 +27,7 @@ struct Epi {
   float limit, extra;
   void* asum;            // A^T-layout products: asum[m] = sum over k of A[k, m] (dtype of out), or NULL
   float* asum_partial;   // split-K: per-split partial sums [splits][M]
+  int64_t m_off;         // row of the whole problem that this launch's row 0 is (dropout stream index)
 };
 
 // sum of a fragment's 8 bf16 values added to s (4 x v_dot2c_f32_bf16 against ones)
@@ -125,7 +126,7 @@ struct EpiVec {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         v[j] = round_as<TI>(v[j]);
-        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
       }
       if (e.aux) {
         Vec4<TI> a;
@@ -164,7 +165,7 @@ struct EpiVec {
       if (e.thr) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          o.v[j] = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
+          o.v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
       }
       o.store((TO*)e.out + m * e.ldo + n);
     } else if (MODE == EPI_DACT) {
@@ -172,7 +173,7 @@ struct EpiVec {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         v[j] = round_as<TI>(v[j]);
-        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
       }
       ACT_SWITCH(e.act, ACT, {
         _Pragma("unroll")
@@ -188,7 +189,7 @@ struct EpiVec {
         pl[j] = p.a.get(j);
         pg[j] = p.b.get(j);
         v[j] = round_as<TI>(v[j]);
-        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)(m * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
         dl.v[j] = v[j];
         dg.v[j] = v[j];
         if (e.use_limit) {
@@ -242,7 +243,7 @@ _Pragma("unroll")
   if (e.thr) {
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      o.v[j] = rng_u32(e.seed, (uint64_t)(m * F + f + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
+      o.v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + f + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
   }
   o.store((TO*)e.out + m * e.ldo + f);
 }
@@ -256,7 +257,7 @@ struct EpiOp {
       ((TO*)e.out)[m * e.ldo + n] = from_f<TO>(v);
     } else if (MODE == VITK_EPI_RESIDUAL) {
       v = round_as<TI>(v);  // the linear's output as the compute dtype holds it
-      if (e.thr) v = rng_u32(e.seed, (uint64_t)(m * e.N + n)) >= e.thr ? round_as<TI>(v * e.keep_scale) : 0.f;
+      if (e.thr) v = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n)) >= e.thr ? round_as<TI>(v * e.keep_scale) : 0.f;
       if (e.aux) ((TI*)e.aux)[m * e.N + n] = from_f<TI>(v);
       const int64_t row = e.row_idx ? e.row_idx[m] : m;
       if (e.gamma) v = round_as<TO>(v * to_f<TO>(((const TO*)e.gamma)[n]));
@@ -1109,7 +1110,7 @@ static Epi make_epi(const VitkGemm* g) {
   e.thr = g->drop_p > 0.f ? drop_threshold(g->drop_p) : 0;
   e.keep_scale = 1.f / (1.f - g->drop_p);
   e.act = g->act; e.use_limit = g->use_limit; e.use_extra = g->use_extra; e.limit = g->limit; e.extra = g->extra_bias;
-  e.asum = g->a_colsum; e.asum_partial = nullptr;
+  e.asum = g->a_colsum; e.asum_partial = nullptr; e.m_off = 0;
   return e;
 }
 
@@ -1173,8 +1174,62 @@ static void launch_mfma_layout(const VitkGemm* g, const Epi& e, int splits, int6
   }
 }
 
+static int64_t cu_count() {
+  static int cached = 0;
+  if (!cached) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
+// A 256^2-tile launch runs one block per CU, so a tile count just above a multiple of the CU count leaves most CUs idle
+// for a whole extra round (816 tiles on 256 CUs: 3.2 rounds cost 4).  Row-major-A problems are then cut in two along M:
+// whole rounds on the 256^2 kernel, the remaining rows on the 128^2 kernel (3 blocks per CU, a quarter of the work
+// per tile).  Returns the number of rows for the first launch, or 0 for no cut.
+static int64_t ragged_round_cut(const VitkGemm* g) {
+  if (g->algo != 0 && g->algo != 2) return 0;
+  if (g->trans_a || !use_tile256(g)) return 0;
+  if (g->epilogue != VITK_EPI_STORE && g->epilogue != VITK_EPI_RESIDUAL) return 0;
+  if (pick_splits(g) != 1) return 0;
+  const int64_t cus = cu_count(), tm = ceil_div(g->M, BM2), tn = ceil_div(g->N, BN2);
+  const int64_t tiles = tm * tn, rounds = tiles / cus, rem = tiles % cus;
+  if (rounds < 1 || rem == 0 || rem * 10 > cus * 6) return 0;     // a last round that is over 60% full stays
+  const int64_t tm_main = rounds * cus / tn;
+  if (tm_main < 1 || tm_main >= tm) return 0;
+  return tm_main * BM2;
+}
+
+template <class TO>
+static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st);
+
+template <class TO>
+static int launch_mfma_cut(const VitkGemm* g, const Epi& e, int64_t m1, hipStream_t st) {
+  const size_t si = 2, so = g->out_dtype == VITK_F32 ? 4 : 2;
+  VitkGemm a = *g, b = *g;
+  a.M = m1;
+  a.algo = 5;                                   // 256^2 tiles, no further cut
+  b.M = g->M - m1;
+  b.algo = 4;                                   // 128^2 tiles
+  b.a = (const char*)g->a + (size_t)m1 * g->lda * si;
+  if (g->row_idx) b.row_idx = g->row_idx + m1;  // gathered rows: out / res stay whole, the index list moves
+  else {
+    b.out = (char*)g->out + (size_t)m1 * g->ldo * so;
+    if (g->res) b.res = (const char*)g->res + (size_t)m1 * g->ldo * so;
+  }
+  if (g->aux) b.aux = (char*)g->aux + (size_t)m1 * g->N * si;
+  Epi ea = make_epi(&a), eb = make_epi(&b);
+  eb.m_off = m1;
+  (void)e;
+  launch_mfma<TO>(&a, ea, st);
+  launch_mfma<TO>(&b, eb, st);
+  return 0;
+}
+
 template <class TO>
 static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st) {
+  if (const int64_t m1 = ragged_round_cut(g)) return launch_mfma_cut<TO>(g, e, m1, st);
   int splits = pick_splits(g);
   if (splits > 1 && (!g->workspace || (size_t)g->workspace_bytes < (size_t)splits * g->M * (g->N + (g->a_colsum ? 1 : 0)) * sizeof(float)))
     splits = 1;

@@ -918,7 +918,11 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;
   const int wm = grp, wn = wid & 3;
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  // A block walks tiles blockIdx.x, + gridDim.x, ... (the host launches one block per CU): a block launch costs a few
+  // microseconds, which is noticeable beside a short-K tile.
+  const int64_t total_tiles = tiles_m * tiles_n * ((K + klen - 1) / klen);
+  for (int64_t vt = blockIdx.x; vt < total_tiles; vt += gridDim.x) {
+  const int64_t wg = xcd_remap(vt, total_tiles);
   int64_t tm, tn, split;
   tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
   const int64_t m0 = tm * BM2, n0 = tn * BN2;
@@ -1014,6 +1018,8 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
     slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
     slab_stage16(stg, acc, sl, lane);
     slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
+  }
+  __syncthreads();   // the staging slabs overlay the ring: done before the next tile's first requests
   }
 #ifdef EXP_STAMP   // diagnostic build: per-block cycle stamps overwrite the start of aux (tools/stamp_gemm.py reads them)
   const uint64_t st3 = __builtin_amdgcn_s_memtime();
@@ -1139,12 +1145,24 @@ static bool use_tile256(const VitkGemm* g) {
   return g->M >= 512 && g->N >= 512 && (g->N >= 1024 || g->K >= 2048);
 }
 
+static int64_t cu_count() {
+  static int cached = 0;
+  if (!cached) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
 template <bool TA, bool TB, int MODE, class TO>
 static void launch_mfma_one(const VitkGemm* g, const Epi& e, int splits, int64_t klen, float* partial, hipStream_t st) {
   if (use_tile256(g)) {
     const int64_t tm = ceil_div(g->M, BM2), tn = ceil_div(g->N, BN2);
     if (g->algo != 3) {   // algo 3 keeps the register-staged 32x32x16 kernel for comparisons
-      hipLaunchKernelGGL((gemm_mfma256d_k<TA, TB, MODE, TO>), dim3((unsigned)(tm * tn * splits)), dim3(512), 0, st,
+      int64_t nblk = tm * tn * splits;
+      if (nblk > cu_count()) nblk = cu_count();   // one resident block per CU (LDS); each walks several tiles
+      hipLaunchKernelGGL((gemm_mfma256d_k<TA, TB, MODE, TO>), dim3((unsigned)nblk), dim3(512), 0, st,
                          (const bf16*)g->a, (const bf16*)g->b, g->M, g->N, g->K, g->lda, g->ldb, tm, tn, klen, e, partial);
       return;
     }
@@ -1172,16 +1190,6 @@ static void launch_mfma_layout(const VitkGemm* g, const Epi& e, int splits, int6
   } else {
     launch_mfma_one<TA, TB, VITK_EPI_STORE, TO>(g, e, 1, klen, nullptr, st);
   }
-}
-
-static int64_t cu_count() {
-  static int cached = 0;
-  if (!cached) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached = n;
-  }
-  return cached;
 }
 
 // A 256^2-tile launch runs one block per CU, so a tile count just above a multiple of the CU count leaves most CUs idle

@@ -1092,13 +1092,18 @@ static int pick_splits(const VitkGemm* g) {
   if (g->epilogue != VITK_EPI_STORE) return 1;
   const bool big = use_tile256(g);
   const int64_t tiles = big ? ceil_div(g->M, BM2) * ceil_div(g->N, BN2) : ceil_div(g->M, BM) * ceil_div(g->N, BN);
-  const int64_t want = big ? 512 : 1024;       // blocks that fill 256 CUs twice (one 256^2 block or three 128^2 per CU)
-  if (tiles >= (big ? 256 : 768) || g->K < 2048) return 1;
-  int64_t s = want / tiles;
-  const int64_t smax = g->K / 1024;
-  if (s > smax) s = smax;
-  if (s > 64) s = 64;
-  return (int)(s < 1 ? 1 : s);
+  const int64_t slots = big ? 256 : 768;       // blocks one round holds: one 256^2 block or three 128^2 blocks per CU
+  if (tiles >= slots || g->K < 2048) return 1;
+  // the fewest splits (least partial traffic) that fill whole rounds to at least 94 %, at most two rounds
+  const int64_t smax = g->K / 1024 < 64 ? g->K / 1024 : 64;
+  int64_t best = 1;
+  double best_eff = 0.0;
+  for (int64_t s = 1; s <= smax && tiles * s <= 2 * slots; s++) {
+    const double eff = (double)(tiles * s) / (double)(ceil_div(tiles * s, slots) * slots);
+    if (eff > best_eff + 1e-9) { best = s; best_eff = eff; }
+    if (eff >= 0.94) { best = s; break; }
+  }
+  return (int)best;
 }
 
 extern "C" size_t vitk_gemm_workspace_bytes(const VitkGemm* g) {

@@ -333,7 +333,10 @@ extern "C" int vitk_norm_fwd(const void* x, int x_dtype, const void* w, const vo
 }
 
 static const int NORM_BWD_BLOCKS = 512;
-extern "C" size_t vitk_norm_bwd_workspace_bytes(int64_t D) { return (size_t)NORM_BWD_BLOCKS * 2 * (size_t)D * sizeof(float); }
+static const int NORM_BWD_FOLD = 16;   // the per-block partials are folded in two steps: 512 -> 16 -> 1 rows
+extern "C" size_t vitk_norm_bwd_workspace_bytes(int64_t D) {
+  return (size_t)(NORM_BWD_BLOCKS + NORM_BWD_FOLD) * 2 * (size_t)D * sizeof(float);
+}
 
 template <class TG, class TX, class TW, class TO, bool LN>
 static int norm_bwd_launch(const void* dy, const void* x, const void* w, const float* rstd, const float* mean,
@@ -387,18 +390,28 @@ extern "C" int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_
   if (rc) return rc;
   VITK_LAUNCH_CHECK("norm_bwd");
   if (want_dw) {
-    // fold the per-block partials [grid][2][D]: dw = first half, db = second half
-    dim3 g2((unsigned)ceil_div(D, 256), 1);
-    const float* ws = (const float*)workspace;
+    // fold the per-block partials [grid][2][D] (dw = first half, db = second half) in two steps, so that the first
+    // one has enough blocks in flight: [grid] -> [NORM_BWD_FOLD] rows (after the partials in the workspace) -> 1 row
+    float* ws = (float*)workspace;
+    float* ws2 = ws + (size_t)NORM_BWD_BLOCKS * 2 * D;
+    const int fold = grid > 4 * NORM_BWD_FOLD ? NORM_BWD_FOLD : 1;
     for (int which = 0; which < 2; which++) {
       void* dst = which == 0 ? dw : db;
       if (!dst) continue;
+      const float* src = ws + (size_t)which * D;
+      int64_t src_ld = 2 * D, src_rows = grid;
+      if (fold > 1) {
+        dim3 g1((unsigned)ceil_div(D, 256), (unsigned)fold);
+        colsum_one<float, float, float>(true, g1, st, src, src_ld, nullptr, (const float*)nullptr, 0, ws2 + (size_t)which * D,
+                                        2 * D, src_rows, D, 1.f);
+        src = ws2 + (size_t)which * D;
+        src_rows = fold;
+      }
+      dim3 g2((unsigned)ceil_div(D, 256), 1);
       if (w_dtype == VITK_F32)
-        colsum_one<float, float, float>(true, g2, st, ws + (size_t)which * D, 2 * D, nullptr, (const float*)nullptr, 0,
-                                        (float*)dst, D, (int64_t)grid, D, 1.f);
+        colsum_one<float, float, float>(true, g2, st, src, src_ld, nullptr, (const float*)nullptr, 0, (float*)dst, D, src_rows, D, 1.f);
       else
-        colsum_one<float, float, bf16>(true, g2, st, ws + (size_t)which * D, 2 * D, nullptr, (const float*)nullptr, 0,
-                                       (bf16*)dst, D, (int64_t)grid, D, 1.f);
+        colsum_one<float, float, bf16>(true, g2, st, src, src_ld, nullptr, (const float*)nullptr, 0, (bf16*)dst, D, src_rows, D, 1.f);
     }
     VITK_LAUNCH_CHECK("norm_bwd reduce");
   }

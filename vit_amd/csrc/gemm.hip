@@ -437,14 +437,121 @@ __device__ __forceinline__ void store_tile(const uint4 (&r)[4], char* s, int tid
 // floats) so that every lane then owns 4 consecutive columns: 16-byte loads of bias/residual, 8/16-byte stores,
 // whole 128-B lines per row.
 // ------------------------------------------------------------------------------------------------
+// ---- 8-column epilogues --------------------------------------------------------------------------
+// bf16 outputs move 8 consecutive columns per lane: 16-byte loads and stores, half as many memory instructions per
+// slab (the epilogues are paced by the issue of their stores).  Used by STORE with bf16 output, GLU and DGLU; their
+// arithmetic (and rounding points) is that of the 4-column forms above.
+template <int MODE, class TO>
+constexpr bool epi_wide() { return MODE == EPI_GLU || MODE == EPI_DGLU || (MODE == VITK_EPI_STORE && sizeof(TO) == 2); }
+
+struct Raw8 {   // 8 bf16 as loaded
+  uint4 q;
+  __device__ __forceinline__ void load(const bf16* p) { q = *(const uint4*)p; }
+  __device__ __forceinline__ float get(int j) const {
+    const uint32_t w = (j >> 1) == 0 ? q.x : (j >> 1) == 1 ? q.y : (j >> 1) == 2 ? q.z : q.w;
+    return __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+};
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; j++) t[j] = (bf16)v[j];
+  *(bf16x8*)p = t;
+}
+
+// GLU forward, 8 pairs: lin[8] = fc1 columns f..f+7, glu[8] = columns F+f..F+f+7 of row m (see epi_glu)
+__device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, float (&lin)[8], float (&glu)[8],
+                                         const float (&bl)[8], const float (&bg)[8]) {
+  typedef bf16 TI;
+  const int64_t F = e.N / 2;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { lin[j] += bl[j]; glu[j] += bg[j]; }
+  store8((TI*)e.aux + m * e.N + f, lin);
+  store8((TI*)e.aux + m * e.N + F + f, glu);
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    lin[j] = round_as<TI>(lin[j]);
+    glu[j] = round_as<TI>(glu[j]);
+    if (e.use_limit) { lin[j] = fminf(fmaxf(lin[j], -e.limit), e.limit); glu[j] = fminf(glu[j], e.limit); }
+    if (e.use_extra) lin[j] = round_as<TI>(lin[j] + e.extra);
+  }
+  ACT_SWITCH(e.act, ACT, {
+_Pragma("unroll")
+    for (int j = 0; j < 8; j++) o[j] = round_as<TI>(act_apply_t<ACT>(glu[j])) * lin[j];
+  });
+  if (e.thr) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + f + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
+  }
+  store8((TI*)e.out + m * e.ldo + f, o);
+}
+
+// DGLU, 8 columns: v = dh[m, n..n+7]; pa / pb = saved linear / gate pre-activations (see EpiVec, EPI_DGLU)
+__device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, float (&v)[8], const Raw8& pa, const Raw8& pb) {
+  typedef bf16 TI;
+  const int64_t F = e.N;
+  float dl[8], dg[8], pl[8], pg[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    pl[j] = pa.get(j);
+    pg[j] = pb.get(j);
+    v[j] = round_as<TI>(v[j]);
+    if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+    dl[j] = v[j];
+    dg[j] = v[j];
+    if (e.use_limit) {
+      const float l = pl[j], gl = pg[j];
+      dl[j] = (l >= -e.limit && l <= e.limit) ? dl[j] : 0.f;
+      dg[j] = (gl <= e.limit) ? dg[j] : 0.f;
+      pl[j] = fminf(fmaxf(l, -e.limit), e.limit);
+      pg[j] = fminf(gl, e.limit);
+    }
+    if (e.use_extra) pl[j] = round_as<TI>(pl[j] + e.extra);
+  }
+  ACT_SWITCH(e.act, ACT, {
+    _Pragma("unroll")
+    for (int j = 0; j < 8; j++) {
+      dl[j] *= round_as<TI>(act_apply_t<ACT>(pg[j]));
+      dg[j] *= pl[j] * act_grad_t<ACT>(pg[j]);
+    }
+  });
+  store8((TI*)e.out + m * e.ldo + n, dl);
+  store8((TI*)e.out + m * e.ldo + F + n, dg);
+}
+
 template <int MODE, class TO>
 struct EpiCols {  // per-lane column constants, loaded once per tile
   float bias0[4], bias1[4], gam[4];
-  int64_t ncol;   // first of this lane's 4 output columns (GLU: the linear column f)
+  float wb0[8], wb1[8];   // 8-column forms
+  int64_t ncol;   // first of this lane's 4 (or 8) output columns (GLU: the linear column f)
   __device__ __forceinline__ void init(const Epi& e, int64_t nwave, int64_t N, int lane) {
 #pragma unroll
     for (int j = 0; j < 4; j++) { bias0[j] = 0.f; bias1[j] = 0.f; gam[j] = 1.f; }
-    if (MODE == EPI_GLU) {
+    if (epi_wide<MODE, TO>()) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { wb0[j] = 0.f; wb1[j] = 0.f; }
+      if (MODE == EPI_GLU) {
+        const int cv = lane & 3;
+        ncol = (nwave >> 6) * 32 + 8 * cv;
+        if (e.bias && nwave + 8 * cv < N) {
+          Raw8 bl, bg;
+          bl.load((const bf16*)e.bias + ncol);
+          bg.load((const bf16*)e.bias + (N >> 1) + ncol);
+#pragma unroll
+          for (int j = 0; j < 8; j++) { wb0[j] = bl.get(j); wb1[j] = bg.get(j); }
+        }
+      } else {
+        ncol = nwave + 8 * (lane & 7);
+        if (e.bias && ncol < N) {
+          Raw8 b;
+          b.load((const bf16*)e.bias + ncol);
+#pragma unroll
+          for (int j = 0; j < 8; j++) wb0[j] = b.get(j);
+        }
+      }
+    } else if (MODE == EPI_GLU) {
       const int cv = lane & 7;
       ncol = (nwave >> 6) * 32 + 4 * cv;
       if (e.bias && nwave + 4 * cv < N) {
@@ -479,7 +586,10 @@ struct EpiCols {  // per-lane column constants, loaded once per tile
 // The staging slab belongs to one wave and LDS operations of a wave complete in order, so no barrier is needed
 // between the steps (the caller has one block barrier between the last main-loop LDS read and the first stage).
 template <int MODE, class TO>
-struct SlabPre { EpiPre<(MODE < 0 ? 0 : MODE), TO> r[8]; };
+struct SlabPre {
+  EpiPre<(MODE < 0 ? 0 : MODE), TO> r[8];
+  Raw8 wa[4], wb[4];   // 8-column DGLU: 4 rows per lane, linear and gate pre-activations
+};
 
 template <int MODE>
 constexpr bool epi_reads_memory() { return MODE == VITK_EPI_RESIDUAL || MODE == VITK_EPI_PATCH || MODE == EPI_DACT || MODE == EPI_DGLU; }
@@ -489,6 +599,18 @@ __device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, 
                                               int64_t mbase, int64_t M, int64_t N, int lane) {
   if (!epi_reads_memory<MODE>()) return;
   constexpr int EMODE = MODE < 0 ? 0 : MODE;
+  if (epi_wide<MODE, TO>()) {   // DGLU
+    const int rr = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int64_t m = mbase + it * 8 + rr;
+      if (m < M && cols.ncol < N) {
+        pre.wa[it].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol);
+        pre.wb[it].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol);
+      }
+    }
+    return;
+  }
   const int rr = lane >> 4;
 #pragma unroll
   for (int it = 0; it < 8; it++) {
@@ -512,7 +634,38 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
                                             int64_t split, float* __restrict__ partial, int lane) {
   constexpr int EMODE = MODE < 0 ? 0 : MODE;
   const int64_t ncol = cols.ncol;
-  if (MODE == EPI_GLU) {
+  if (epi_wide<MODE, TO>() && MODE == EPI_GLU) {
+    const int cv = lane & 3, rr = lane >> 2;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int row = it * 16 + rr;
+      const int64_t m = mbase + row;
+      float lin[8], glu[8];
+      *(float4*)lin = *(const float4*)(stg + row * STG_LD + 8 * cv);
+      *(float4*)(lin + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
+      *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv);
+      *(float4*)(glu + 4) = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv + 4);
+      if (m < M && nwave + 8 * cv < N) epi_glu8(e, m, ncol, lin, glu, cols.wb0, cols.wb1);
+    }
+  } else if (epi_wide<MODE, TO>()) {
+    const int cv = lane & 7, rr = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + rr;
+      const int64_t m = mbase + row;
+      float v[8];
+      *(float4*)v = *(const float4*)(stg + row * STG_LD + 8 * cv);
+      *(float4*)(v + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
+      if (m < M && ncol < N) {
+        if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, v, pre.wa[it], pre.wb[it]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
+          store8((bf16*)e.out + m * e.ldo + ncol, v);
+        }
+      }
+    }
+  } else if (MODE == EPI_GLU) {
     const int cv = lane & 7, rr = lane >> 3;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
@@ -1066,8 +1219,10 @@ static bool mfma_ok(const VitkGemm* g) {
   if ((ep == VITK_EPI_RESIDUAL || ep == VITK_EPI_PATCH || ep == VITK_EPI_ACT || ep == VITK_EPI_GLU) && !nt) return false;
   if ((ep == VITK_EPI_DACT || ep == VITK_EPI_DGLU) && !nn) return false;
   if (ep == VITK_EPI_GLU && g->N % 64) return false;
-  // the epilogue moves 4 columns per lane with vector accesses
+  // the epilogue moves 4 columns per lane with vector accesses, 8 for bf16 outputs of STORE / GLU / DGLU
   if (g->N % 4 || g->ldo % 4) return false;
+  if (g->out_dtype == VITK_BF16 && (ep == VITK_EPI_STORE || ep == VITK_EPI_GLU || ep == VITK_EPI_DGLU) && (g->N % 8 || g->ldo % 8))
+    return false;
   if (!aligned16(g->out) || !aligned16(g->res) || !aligned16(g->aux) || !aligned16(g->bias) || !aligned16(g->gamma) ||
       !aligned16(g->pos))
     return false;

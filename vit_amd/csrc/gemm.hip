@@ -473,8 +473,14 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, flo
   for (int j = 0; j < 8; j++) {
     lin[j] = round_as<TI>(lin[j]);
     glu[j] = round_as<TI>(glu[j]);
-    if (e.use_limit) { lin[j] = fminf(fmaxf(lin[j], -e.limit), e.limit); glu[j] = fminf(glu[j], e.limit); }
-    if (e.use_extra) lin[j] = round_as<TI>(lin[j] + e.extra);
+  }
+  if (e.use_limit || e.use_extra) {   // off in the usual configuration: a real (uniform) branch, not selects per element
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (e.use_limit) { lin[j] = fminf(fmaxf(lin[j], -e.limit), e.limit); glu[j] = fminf(glu[j], e.limit); }
+      if (e.use_extra) lin[j] = round_as<TI>(lin[j] + e.extra);
+    }
   }
   ACT_SWITCH(e.act, ACT, {
 _Pragma("unroll")
@@ -501,14 +507,20 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, fl
     if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
     dl[j] = v[j];
     dg[j] = v[j];
-    if (e.use_limit) {
-      const float l = pl[j], gl = pg[j];
-      dl[j] = (l >= -e.limit && l <= e.limit) ? dl[j] : 0.f;
-      dg[j] = (gl <= e.limit) ? dg[j] : 0.f;
-      pl[j] = fminf(fmaxf(l, -e.limit), e.limit);
-      pg[j] = fminf(gl, e.limit);
+  }
+  if (e.use_limit || e.use_extra) {   // a real (uniform) branch: see epi_glu8
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (e.use_limit) {
+        const float l = pl[j], gl = pg[j];
+        dl[j] = (l >= -e.limit && l <= e.limit) ? dl[j] : 0.f;
+        dg[j] = (gl <= e.limit) ? dg[j] : 0.f;
+        pl[j] = fminf(fmaxf(l, -e.limit), e.limit);
+        pg[j] = fminf(gl, e.limit);
+      }
+      if (e.use_extra) pl[j] = round_as<TI>(pl[j] + e.extra);
     }
-    if (e.use_extra) pl[j] = round_as<TI>(pl[j] + e.extra);
   }
   ACT_SWITCH(e.act, ACT, {
     _Pragma("unroll")

@@ -137,9 +137,11 @@ int vitk_attn_bwd(const VitkAttn* a, void* stream);
 /* ---- RoPE: vit/rope.py:139-163 (apply_rope: half-split rotation, prefix rows untouched) -------------
  * In place on the q and k sections of the packed projection qkv[B*S, 3*H*Dh]. table = [2, S-prefix, Dh]
  * fp32 (sin then cos).  inverse = 1 applies the transpose (backward).  emulate_bf16 = 1 rounds each
- * product and the sum to bf16 like eager bf16 arithmetic does when the table itself is bf16. */
+ * product and the sum to bf16 like eager bf16 arithmetic does when the table itself is bf16.
+ * per_sample = 1: table = [2, B, S-prefix, Dh], one table per sample -- the masked-token path, where every
+ * sample keeps its own subset of positions (vit/vit.py:522-527, vit/rope.py:139-163 with a 5-D table). */
 int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
-                 int64_t prefix, int inverse, int emulate_bf16, void* stream);
+                 int64_t prefix, int inverse, int emulate_bf16, int per_sample, void* stream);
 
 /* ---- MLP activation: vit/fused.py:115-116 (plain) and :154-161 (GLU), vit/helpers.py:9-48 ----------
  * plain: h = dropout(act(p));  GLU: lin = p[:, :F], glu = p[:, F:], h = dropout(act(min(glu,limit)) *

@@ -44,7 +44,15 @@ CASES = {
                                 attention_bias=False, mlp_bias=False), 2, (32, 32), "fp32"),
     "g09_relu_none_layernorm_fp32": (dict(activation="relu", pos_enc="none", norm_type="layernorm", num_cls_tokens=2), 2, (32, 32), "fp32"),
     "g10_geglu_resize_fp32": (dict(activation="geglu", pos_enc="fourier", num_register_tokens=3), 2, (48, 40), "fp32"),
+    # masked-token forward (vit/vit.py:545, :522-527): a fixed non-ragged mask is part of the fixture ("mask" key)
+    "g11_masked_rope_fp32": (dict(activation="srelu", pos_enc="rope", num_register_tokens=2, img_size=(32, 48)), 3, (32, 48), "fp32"),
+    "g11_masked_rope_autocast": (dict(activation="swiglu", pos_enc="rope", num_register_tokens=2, img_size=(32, 48)), 3, (32, 48),
+                                 "autocast_bf16"),
+    "g11_masked_fourier_droppath_fp32": (dict(activation="swiglu", pos_enc="fourier", num_register_tokens=1, drop_path_rate=0.25,
+                                              layer_scale=0.1), 8, (32, 32), "fp32"),
+    "g11_masked_rope_droppath_fp32": (dict(activation="srelu", pos_enc="rope", drop_path_rate=0.25), 8, (32, 32), "fp32"),
 }
+MASKED = {k for k in CASES if k.startswith("g11_masked")}
 
 
 def plain_cfg(cfg) -> dict:
@@ -81,18 +89,25 @@ def make(ref, name, overrides, B, hw, mode, seed):
     perturb(model, gen)
     x = torch.randn(B, cfg.in_channels, *hw, generator=gen).to(cfg.dtype)
     ac = torch.autocast("cpu", dtype=torch.bfloat16, enabled=(mode == "autocast_bf16"))
+    mask = None
+    if name in MASKED:   # keep 5/8 of the tokens of every sample (a non-ragged mask, as the reference's create_mask makes)
+        L = (hw[0] // cfg.patch_size[0]) * (hw[1] // cfg.patch_size[1])
+        keep = (5 * L) // 8
+        mask = torch.zeros(B, L, dtype=torch.bool)
+        for b in range(B):
+            mask[b, torch.randperm(L, generator=gen)[:keep]] = True
 
     model.eval()
     with torch.no_grad(), ac:
-        eval_out = model(x).dense_features.clone()
-        eval_out_nonorm = model(x, output_norm=False).dense_features.clone()
+        eval_out = model(x, mask).dense_features.clone()
+        eval_out_nonorm = model(x, mask, output_norm=False).dense_features.clone()
 
     model.train()
     xg = x.clone().requires_grad_(True)
     train_seed = seed + 101
     torch.manual_seed(train_seed)
     with ac:
-        out = model(xg).dense_features
+        out = model(xg, mask).dense_features
     out.float().square().mean().backward()
     fix = {
         "cfg": plain_cfg(cfg),
@@ -106,6 +121,8 @@ def make(ref, name, overrides, B, hw, mode, seed):
         "grads": {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
         "train_seed": train_seed,
     }
+    if mask is not None:
+        fix["mask"] = mask
     path = os.path.join(OUT, name + ".pt")
     torch.save(fix, path)
     print(f"{name:45s} out={tuple(eval_out.shape)} {eval_out.dtype} bytes={os.path.getsize(path)}")
@@ -146,9 +163,13 @@ def main():
     ref = refshim.import_reference()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # fixed reduction order
+    only = sys.argv[1:]   # optional name prefixes: regenerate just those fixtures (seeds do not depend on the selection)
     for i, (name, (ov, B, hw, mode)) in enumerate(CASES.items()):
+        if only and not any(name.startswith(p) for p in only):
+            continue
         make(ref, name, ov, B, hw, mode, seed=1000 + i)
-    make_op_level(ref)
+    if not only or any("g07_ops".startswith(p) for p in only):
+        make_op_level(ref)
 
 
 if __name__ == "__main__":

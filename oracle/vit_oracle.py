@@ -243,11 +243,33 @@ def merge_residual_subset(x: Tensor, o: Tensor, idx: Tensor | None, scale: float
     return x.flatten(1).index_add(0, idx, o.flatten(1), alpha=scale).view_as(x)
 
 
+def subset_batched_rope(rope: Tensor | None, idx: Tensor | None, full_batch: int) -> Tensor | None:
+    """vit/transformer.py:41-46: a per-sample table [2, B, 1, N, Dh] follows the drop-path subset."""
+    if rope is None or idx is None:
+        return rope
+    if rope.ndim == 5 and rope.shape[1] == full_batch:
+        return rope.index_select(1, idx)
+    return rope
+
+
+def apply_token_mask(mask: Tensor, x: Tensor) -> Tensor:
+    """vit/tokens.py:58-94 with fill_value=None and padding 0: kept tokens (mask True) in order, samples with fewer
+    kept tokens padded with zeros at the end."""
+    B, L, D = x.shape
+    counts = mask.sum(dim=-1)
+    width = int(counts.max())
+    out = x.new_zeros((B, width, D))
+    for b in range(B):
+        rows = x[b][mask[b]]
+        out[b, : rows.shape[0]] = rows
+    return out
+
+
 def encoder_layer(cfg: OracleConfig, sd: dict, i: int, x: Tensor, rope: Tensor | None, training: bool) -> Tensor:
     """vit/transformer.py:146-157; layer scale = vit/layer_scale.py:8-13 (out-of-place form)."""
     pre = f"blocks.{i}."
     xr, idx, scale = select_residual_subset(x, cfg.drop_path_rate, training)
-    o = self_attention(cfg, sd, pre + "self_attention.", xr, rope, training)
+    o = self_attention(cfg, sd, pre + "self_attention.", xr, subset_batched_rope(rope, idx, x.shape[0]), training)
     if cfg.layer_scale is not None:
         o = o * sd[pre + "layer_scale_attn.gamma"]
     x = merge_residual_subset(x, o, idx, scale)
@@ -273,20 +295,27 @@ def patch_embed(cfg: OracleConfig, sd: dict, x: Tensor, training: bool) -> Tenso
 
 
 def vit_forward(cfg: OracleConfig, sd: dict, x: Tensor, *, training: bool = False, output_norm: bool = True,
-                rope_seed: int | None = None) -> Tensor:
-    """vit/vit.py:534-561 without the mask branch; returns ``dense_features`` [B, S, D]."""
+                rope_seed: int | None = None, mask: Tensor | None = None) -> Tensor:
+    """vit/vit.py:534-561; returns ``dense_features`` [B, S, D].  ``mask`` [B, L] bool (True = kept token) is the
+    masked-token branch: vit/vit.py:545 and :522-527."""
     ln = cfg.norm_type == "layernorm"
     dims = tuple(s // q for s, q in zip(x.shape[2:], cfg.patch_size))
     x = patch_embed(cfg, sd, x, training)
     if cfg.patch_embed_normalization:
         x = apply_norm(x, sd["patch_embed_norm.weight"], sd.get("patch_embed_norm.bias"), None, ln)
     B = x.shape[0]
+    if mask is not None:
+        x = apply_token_mask(mask, x)
     x = torch.cat([sd["cls_tokens"].expand(B, -1, -1), sd["register_tokens"].expand(B, -1, -1), x], dim=1)
     rope = None
     if cfg.pos_enc == "rope":
         rope = rope_table(dims[0], dims[1], sd["rope.periods"], cfg.dtype, training=training,
                           shift=cfg.rope_shift_coords, jitter=cfg.rope_jitter_coords,
                           rescale=cfg.rope_rescale_coords, rope_seed=rope_seed)
+        if mask is not None:
+            sin = apply_token_mask(mask, rope[0][None].expand(B, -1, -1))
+            cos = apply_token_mask(mask, rope[1][None].expand(B, -1, -1))
+            rope = torch.stack([sin[:, None], cos[:, None]], dim=0)
     for i in range(cfg.depth):
         if cfg.activation_checkpointing and training:
             x = checkpoint(lambda t, r, _i=i: encoder_layer(cfg, sd, _i, t, r, training), x, rope, use_reentrant=False)
@@ -387,7 +416,7 @@ def randomize_state(sd: dict, seed: int = 1, scale: float = 1.0) -> dict:
 
 def run_fwd_bwd(cfg: OracleConfig, sd: dict, x: Tensor, *, training: bool = True, autocast: torch.dtype | None = None,
                 loss: str = "square_mean", seed: int | None = None, x_requires_grad: bool = True,
-                output_norm: bool = True) -> dict[str, Any]:
+                output_norm: bool = True, mask: Tensor | None = None) -> dict[str, Any]:
     """Forward + backward with the loss of the reference's own parity test (tests/test_vit.py:841-846:
     ``dense_features.float().square().mean()``) or its benchmark (benchmark/benchmark.py:203-209: ``mean``)."""
     params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k != "rope.periods" and v.numel() > 0)
@@ -397,7 +426,7 @@ def run_fwd_bwd(cfg: OracleConfig, sd: dict, x: Tensor, *, training: bool = True
         torch.manual_seed(seed)
     ctx = torch.autocast(x.device.type, dtype=autocast) if autocast is not None else torch.autocast(x.device.type, enabled=False)
     with ctx:
-        y = vit_forward(cfg, params, xi, training=training, output_norm=output_norm)
+        y = vit_forward(cfg, params, xi, training=training, output_norm=output_norm, mask=mask)
     val = y.float().square().mean() if loss == "square_mean" else y.mean()
     val.backward()
     grads = {k: p.grad for k, p in params.items() if p.requires_grad and p.grad is not None}

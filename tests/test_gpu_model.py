@@ -33,32 +33,29 @@ def build(fix_cfg: dict, state: dict):
     return cfg, model
 
 
-def run_train(model, x, autocast, seed, loss="square_mean"):
+def run_train(model, x, autocast, seed, loss="square_mean", mask=None):
     model.train()
     model.zero_grad(set_to_none=True)
     xg = x.clone().requires_grad_(True)
     torch.manual_seed(seed)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-        out = model(xg).dense_features
+        out = model(xg, mask).dense_features
     val = out.float().square().mean() if loss == "square_mean" else out.mean()
     val.backward()
     return out.detach(), xg.grad, {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
 
 
 # g03 trains with dropout on the learnable position table (CPU RNG stream of the fixture cannot be replayed on
-# the GPU); g07_qknorm needs qk_normalization (not built yet).
+# the GPU).
 TRAIN_SKIP = {"g03_layernorm_gelu_learnable_cls_fp32"}
-UNSUPPORTED = {"g07_qknorm_fp32"}
-# g04 draws the drop-path subset with torch.randperm on the CPU generator in the fixture; the GPU generator
+# These draw the drop-path subset with torch.randperm on the CPU generator in the fixture; the GPU generator
 # draws a different permutation, so the train pass is compared against the oracle on the GPU instead.
-RANDPERM = {"g04_droppath_layerscale_fp32"}
+RANDPERM = {"g04_droppath_layerscale_fp32", "g11_masked_fourier_droppath_fp32", "g11_masked_rope_droppath_fp32"}
 
 
 @pytest.mark.parametrize("name", golden_names())
 @pytest.mark.parametrize("algo", [0, 1])
 def test_golden_fixture(name, algo):
-    if name in UNSUPPORTED:
-        pytest.skip("qk_normalization is not built yet")
     fix = load_golden(name)
     mode = fix["mode"]
     if algo == 1 and mode == "fp32":
@@ -67,18 +64,19 @@ def test_golden_fixture(name, algo):
     try:
         cfg, model = build(fix["cfg"], fix["state"])
         x = fix["x"].to(DEV)
+        mask = fix["mask"].to(DEV) if "mask" in fix else None   # masked-token fixtures
         ac = mode == "autocast_bf16"
         rtol = 1e-4 if mode == "fp32" else 2e-2
         model.eval()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
-            ev = model(x).dense_features
-            ev2 = model(x, output_norm=False).dense_features
+            ev = model(x, mask).dense_features
+            ev2 = model(x, mask, output_norm=False).dense_features
         assert ev.dtype == fix["eval_out"].dtype
         close(ev, fix["eval_out"], rtol, "eval_out")
         close(ev2, fix["eval_out_nonorm"], rtol, "eval_out_nonorm")
         if name in TRAIN_SKIP or name in RANDPERM:
             return
-        out, xg, grads = run_train(model, x, ac, fix["train_seed"])
+        out, xg, grads = run_train(model, x, ac, fix["train_seed"], mask=mask)
         close(out, fix["train_out"], rtol, "train_out")
         grtol = rtol if mode == "fp32" else 5e-2
         close(xg, fix["x_grad"], grtol, "x_grad", atol_scale=2.0)
@@ -95,7 +93,7 @@ def oracle_cfg(cfg) -> "O.OracleConfig":
 
 
 def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_mean", grad_rtol=None, state_seed=3,
-                               oracle_device="cpu"):
+                               oracle_device="cpu", keep_ratio=None):
     """Same weights, same input: vit_amd (HIP kernels) vs the oracle's torch ops.  The oracle runs on the CPU unless
     the case draws random numbers on the device (drop-path's randperm); then it runs on the GPU with the same
     torch.manual_seed, with MIOpen and the fused SDPA backends switched off so it uses plain ATen math."""
@@ -104,10 +102,16 @@ def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_
     model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, cfg.in_channels, *hw, generator=g).to(cfg.dtype)
-    out, xg, grads = run_train(model, x.to(DEV), autocast, 1234, loss)
+    mask = None
+    if keep_ratio is not None:   # the same number of kept tokens in every sample, positions drawn per sample
+        L = (hw[0] // cfg.patch_size[0]) * (hw[1] // cfg.patch_size[1])
+        mask = torch.zeros(B, L, dtype=torch.bool)
+        for b in range(B):
+            mask[b, torch.randperm(L, generator=g)[: int(L * keep_ratio)]] = True
+    out, xg, grads = run_train(model, x.to(DEV), autocast, 1234, loss, mask=None if mask is None else mask.to(DEV))
     ac = torch.bfloat16 if autocast else None
     if oracle_device == "cpu":
-        ref = O.run_fwd_bwd(oracle_cfg(cfg), sd, x, training=True, autocast=ac, loss=loss, seed=1234)
+        ref = O.run_fwd_bwd(oracle_cfg(cfg), sd, x, training=True, autocast=ac, loss=loss, seed=1234, mask=mask)
     else:
         from torch.nn.attention import SDPBackend, sdpa_kernel
 
@@ -116,7 +120,7 @@ def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_
         try:
             with sdpa_kernel(SDPBackend.MATH):
                 ref = O.run_fwd_bwd(oracle_cfg(cfg), {k: v.to(DEV) for k, v in sd.items()}, x.to(DEV), training=True,
-                                    autocast=ac, loss=loss, seed=1234)
+                                    autocast=ac, loss=loss, seed=1234, mask=None if mask is None else mask.to(DEV))
         finally:
             torch.backends.cudnn.enabled = old
     assert out.dtype == ref["out"].dtype
@@ -134,6 +138,36 @@ def test_drop_path_layer_scale_matches_oracle_fp32():
                     num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="srelu", pos_enc="rope",
                     layer_scale=0.1, drop_path_rate=0.25, num_register_tokens=2, dtype=torch.float32)
     compare_with_oracle_on_gpu(cfg, 8, (32, 32), False, 1e-4, oracle_device="cuda")
+
+
+@pytest.mark.parametrize("pos_enc", ["rope", "fourier"])
+def test_masked_tokens_with_drop_path_match_oracle_fp32(pos_enc):
+    """Masked-token forward (vit/vit.py:545, :522-527) together with drop-path, whose subset also selects the
+    per-sample RoPE tables (vit/transformer.py:41-46)."""
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 48), depth=3, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc=pos_enc,
+                    layer_scale=0.1, drop_path_rate=0.25, num_register_tokens=2, dtype=torch.float32)
+    compare_with_oracle_on_gpu(cfg, 8, (32, 48), False, 1e-4, oracle_device="cuda", keep_ratio=0.5)
+
+
+@pytest.mark.parametrize("mode", ["autocast", "bf16"])
+def test_masked_tokens_match_oracle_bf16(mode):
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(64, 64), depth=2, hidden_size=128, ffn_hidden_size=256,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="rope",
+                    num_register_tokens=4, dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+    compare_with_oracle_on_gpu(cfg, 4, (64, 64), mode == "autocast", 2e-2, grad_rtol=5e-2, keep_ratio=0.375)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "autocast", "bf16"])
+@pytest.mark.parametrize("norm_type", ["rmsnorm", "layernorm"])
+def test_qk_normalization_matches_oracle(mode, norm_type):
+    """Per-head q/k normalisation before RoPE (vit/attention.py:25-41)."""
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 48), depth=2, hidden_size=128, ffn_hidden_size=256,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="srelu", pos_enc="rope",
+                    qk_normalization=True, norm_type=norm_type, num_register_tokens=2,
+                    dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+    rtol = 1e-4 if mode == "fp32" else 2e-2
+    compare_with_oracle_on_gpu(cfg, 3, (32, 48), mode == "autocast", rtol, grad_rtol=None if mode == "fp32" else 5e-2)
 
 
 def test_activation_checkpointing_equals_plain_fp32():

@@ -179,3 +179,87 @@ def test_ctypes_struct_layout_matches_header_field_order():
             parts = [re.sub(r"[*\s]", "", piece.split()[-1]) for piece in stmt.split(",")]
             names += parts
         assert names == [f[0] for f in cls._fields_], cname
+
+
+# ---- token masks (vit/tokens.py): the cases of the reference's tests/test_tokens.py:10-57 ----------------------
+@pytest.mark.parametrize("mask, exp", [
+    (([True, True], [True, True]), False),
+    (([True, False], [True, True]), True),
+    (([False, True], [True, True]), True),
+    (([False, False], [True, True]), True),
+    (([False, False], [False, False]), False),
+])
+def test_mask_is_ragged(mask, exp):
+    from vit_amd.tokens import mask_is_ragged
+
+    assert mask_is_ragged(torch.tensor(mask, dtype=torch.bool)) == exp
+
+
+@pytest.mark.parametrize("mask, fill_value, padding_value, exp", [
+    (([True, True], [True, True]), None, 0, [[0, 1], [0, 1]]),
+    (([True, False], [False, True]), None, 0, [[0], [1]]),
+    (([False, True], [True, False]), None, 0, [[1], [0]]),
+    (([False, False], [False, False]), None, 0, [[], []]),
+    (([True, False], [False, True]), -1.0, 0, [[0, -1.0], [-1.0, 1]]),
+    (([True, False], [False, True]), torch.tensor(-1.0), 0, [[0, -1.0], [-1.0, 1]]),
+    (([True, False], [True, True]), None, 0, [[0, 0], [0, 1]]),
+    (([False, True], [True, True]), None, 0, [[1, 0], [0, 1]]),
+    (([True, False], [True, True]), None, -1.0, [[0, -1.0], [0, 1]]),
+    (([False, True], [True, True]), None, -1.0, [[1, -1.0], [0, 1]]),
+    (([False, True], [True, True]), -1.0, 0, [[-1.0, 1], [0, 1]]),
+])
+def test_apply_mask_cases(mask, fill_value, padding_value, exp):
+    from vit_amd.tokens import apply_mask
+
+    mask = torch.tensor(mask, dtype=torch.bool)
+    N, L = mask.shape
+    x = torch.arange(L).view(1, L, 1).expand(N, L, 1)
+    o = apply_mask(mask, x, fill_value, padding_value)
+    assert torch.equal(o.float().reshape(N, -1), torch.tensor(exp).float().reshape(N, -1))
+
+
+@pytest.mark.parametrize("size, ratio, scale, roll", [((8, 8), 0.5, 1, False), ((8, 12), 0.25, 2, False),
+                                                      ((16, 16), 0.75, 4, True), ((10,), 0.3, 1, False)])
+def test_create_mask_drops_the_requested_share(size, ratio, scale, roll):
+    from vit_amd.tokens import apply_mask, create_mask, mask_is_ragged, unapply_mask
+
+    torch.manual_seed(0)
+    B = 6
+    L = 1
+    for s in size:
+        L *= s
+    mask = create_mask(size, ratio, batch_size=B, scale=scale, roll=roll)
+    assert mask.shape == (B, L) and mask.dtype == torch.bool and not mask_is_ragged(mask)
+    coarse = L // scale ** len(size)
+    assert int((~mask[0]).sum()) == round(coarse * ratio) * scale ** len(size)
+    assert not torch.equal(mask[0], mask[1])   # drawn per sample
+    x = torch.randn(B, L, 5)
+    back = unapply_mask(mask, apply_mask(mask, x))
+    assert torch.equal(back[mask], x[mask]) and bool((back[~mask] == 0).all())
+    with pytest.raises(ValueError):
+        create_mask(size, 1.5)
+
+
+def test_generate_non_overlapping_mask():   # tests/test_tokens.py:147-170
+    from vit_amd.tokens import create_mask, generate_non_overlapping_mask
+
+    torch.manual_seed(1)
+    m1 = ~create_mask((100,), 0.4, batch_size=4)   # True = selected by the first mask
+    m2 = generate_non_overlapping_mask(m1, 0.4, 0.3)
+    assert not bool((m1 & m2).any()) and bool((m2.sum(1) == 30).all())
+    with pytest.raises(ValueError):
+        generate_non_overlapping_mask(m1, 0.6, 0.6)
+
+
+def test_masked_rope_table_is_per_sample():   # vit/vit.py:507-529
+    cfg = small(pos_enc="rope")
+    model = cfg.instantiate()
+    x = torch.zeros(3, cfg.in_channels, *cfg.img_size)
+    mask = model.create_mask(x, unmasked_ratio=0.5, scale=1)
+    grid = model.stem.tokenized_size(tuple(cfg.img_size))
+    full = model.prepare_rope(grid)
+    per = model.prepare_rope(grid, mask)
+    kept = int(mask[0].sum())
+    assert per.shape == (2, 3, 1, kept, full.shape[-1])
+    for b in range(3):
+        assert torch.equal(per[0, b, 0], full[0][mask[b]]) and torch.equal(per[1, b, 0], full[1][mask[b]])

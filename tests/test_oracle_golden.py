@@ -25,15 +25,16 @@ def test_oracle_matches_reference_fixture(name):
     cfg = cfg_from(fix)
     ac = torch.bfloat16 if fix["mode"] == "autocast_bf16" else None
     sd, x = fix["state"], fix["x"]
+    mask = fix.get("mask")   # masked-token fixtures carry the mask the reference was run with
     torch.set_num_threads(1)
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=ac is not None):
-        ev = O.vit_forward(cfg, sd, x, training=False)
-        ev2 = O.vit_forward(cfg, sd, x, training=False, output_norm=False)
+        ev = O.vit_forward(cfg, sd, x, training=False, mask=mask)
+        ev2 = O.vit_forward(cfg, sd, x, training=False, output_norm=False, mask=mask)
     torch.testing.assert_close(ev, fix["eval_out"], **tol(fix["mode"]))
     torch.testing.assert_close(ev2, fix["eval_out_nonorm"], **tol(fix["mode"]))
     assert ev.dtype == fix["eval_out"].dtype
 
-    r = O.run_fwd_bwd(cfg, sd, x, training=True, autocast=ac, seed=fix["train_seed"])
+    r = O.run_fwd_bwd(cfg, sd, x, training=True, autocast=ac, seed=fix["train_seed"], mask=mask)
     torch.testing.assert_close(r["out"], fix["train_out"], **tol(fix["mode"]))
     torch.testing.assert_close(r["x_grad"], fix["x_grad"], **tol(fix["mode"]))
     assert set(r["grads"]) == set(fix["grads"])

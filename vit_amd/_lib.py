@@ -80,7 +80,7 @@ def load() -> C.CDLL:
         "vitk_gemm": [C.POINTER(VitkGemm), vp],
         "vitk_attn_fwd": [C.POINTER(VitkAttn), vp],
         "vitk_attn_bwd": [C.POINTER(VitkAttn), vp],
-        "vitk_rope_qk": [vp, i32, vp, i64, i64, i64, i64, i64, i32, i32, vp],
+        "vitk_rope_qk": [vp, i32, vp, i64, i64, i64, i64, i64, i32, i32, i32, vp],
         "vitk_act_fwd": [vp, vp, i32, i64, i64, i32, i32, i32, f32, i32, f32, f32, u64, vp],
         "vitk_act_bwd": [vp, vp, vp, i32, i64, i64, i32, i32, i32, f32, i32, f32, f32, u64, vp],
         "vitk_im2col": [vp, i32, vp, i32, i64, i64, i64, i64, i64, i64, i64, vp],

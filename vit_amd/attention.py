@@ -17,9 +17,11 @@ from .initialization import init_linear
 from .norm import get_norm_bias, is_layer_norm, make_norm
 
 
-def _sublayer_opts(*, head_dim, eps, layernorm, attention_dropout, dropout, training, residual, alpha=1.0):
+def _sublayer_opts(*, head_dim, eps, layernorm, attention_dropout, dropout, training, residual, alpha=1.0,
+                   qk_eps=1e-5, qk_layernorm=False):
     return dict(head_dim=head_dim, eps=float(eps), layernorm=bool(layernorm), attention_dropout=float(attention_dropout),
-                dropout=float(dropout), training=bool(training), residual=residual, alpha=float(alpha))
+                dropout=float(dropout), training=bool(training), residual=residual, alpha=float(alpha),
+                qk_eps=float(qk_eps), qk_layernorm=bool(qk_layernorm))
 
 
 def attention_qkv_packed(x, w_in, b_in, w_norm, b_norm, use_layer_norm, head_dim, w_out, b_out, attn_mask, eps,
@@ -30,10 +32,13 @@ def attention_qkv_packed(x, w_in, b_in, w_norm, b_norm, use_layer_norm, head_dim
     if attn_mask is not None:
         raise NotImplementedError("vit_amd: attention masks are not on the ViT encoder path (vit/transformer.py:151)")
     if qk_normalization:
-        raise NotImplementedError("vit_amd: qk_normalization is not implemented yet")
+        assert q_norm_weight is not None and k_norm_weight is not None
+    else:
+        q_norm_weight = q_norm_bias = k_norm_weight = k_norm_bias = None
     opt = _sublayer_opts(head_dim=head_dim, eps=eps, layernorm=use_layer_norm, attention_dropout=attention_dropout,
-                         dropout=dropout, training=training, residual=False)
-    return ops.AttentionSublayerFn.apply(x, w_norm, b_norm, w_in, b_in, w_out, b_out, None, rope, None, opt)
+                         dropout=dropout, training=training, residual=False, qk_eps=qk_eps, qk_layernorm=qk_use_layer_norm)
+    return ops.AttentionSublayerFn.apply(x, w_norm, b_norm, w_in, b_in, w_out, b_out, None, rope, None, q_norm_weight,
+                                         q_norm_bias, k_norm_weight, k_norm_bias, opt)
 
 
 class SelfAttention(nn.Module):
@@ -71,18 +76,24 @@ class SelfAttention(nn.Module):
     def fused_residual(self, x: Tensor, rope: Optional[Tensor], gamma: Optional[Tensor], keep_idx: Optional[Tensor],
                        alpha: float) -> Tensor:
         """x (+) alpha * gamma * attention(x[keep_idx]) with residual, layer scale and drop-path merge fused."""
-        if self._qk_normalization:
-            raise NotImplementedError("vit_amd: qk_normalization is not implemented yet")
+        qw, qb, kw_, kb, qk_eps = self._qk_norm_inputs()
         opt = _sublayer_opts(head_dim=self._head_dim, eps=self.norm.eps or 1e-5, layernorm=self._use_layer_norm,
                              attention_dropout=self.attention_dropout.p, dropout=self.dropout.p, training=self.training,
-                             residual=True, alpha=alpha)
+                             residual=True, alpha=alpha, qk_eps=qk_eps, qk_layernorm=self._use_layer_norm)
         return ops.AttentionSublayerFn.apply(x, self.norm.weight, get_norm_bias(self.norm), self.qkv_proj.weight,
                                              self.qkv_proj.bias, self.out_proj.weight, self.out_proj.bias, gamma, rope,
-                                             keep_idx, opt)
+                                             keep_idx, qw, qb, kw_, kb, opt)
+
+    def _qk_norm_inputs(self):
+        """(q weight, q bias, k weight, k bias, eps), all None / 1e-5 without qk_normalization (vit/attention.py:61-68)."""
+        if self.q_norm is None or self.k_norm is None:
+            return None, None, None, None, 1e-5
+        return (self.q_norm.weight, get_norm_bias(self.q_norm), self.k_norm.weight, get_norm_bias(self.k_norm),
+                self.q_norm.eps or 1e-5)
 
     def forward(self, x: Tensor, attn_mask: Optional[Tensor] = None, rope: Optional[Tensor] = None) -> Tensor:
         return attention_qkv_packed(
             x, self.qkv_proj.weight, self.qkv_proj.bias, self.norm.weight, get_norm_bias(self.norm), self._use_layer_norm,
             self._head_dim, self.out_proj.weight, self.out_proj.bias, attn_mask, self.norm.eps or 1e-5,
-            None, None, None, None, self._use_layer_norm, 1e-5, self._qk_normalization,
+            *self._qk_norm_inputs()[:4], self._use_layer_norm, self._qk_norm_inputs()[4], self._qk_normalization,
             self.attention_dropout.p, self.dropout.p, self.training, rope)

@@ -561,13 +561,15 @@ extern "C" int vitk_act_bwd(const void* dh, const void* p, void* dp, int dtype, 
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const float* __restrict__ table, int64_t B,
-                                                 int64_t S, int64_t H, int64_t Dh, int64_t prefix, int inverse, int emu) {
+                                                 int64_t S, int64_t H, int64_t Dh, int64_t prefix, int inverse, int emu,
+                                                 int per_sample) {
   const int64_t half = Dh / 2;
   const int64_t np = half / 2;          // pairs per head
   const int64_t N = S - prefix;         // rotated rows per sample
   const int64_t total = B * N * 2 * H * np;
+  const int64_t tbs = per_sample ? N * Dh : 0;   // table stride between samples
   const float* sinT = table;
-  const float* cosT = table + N * Dh;
+  const float* cosT = table + (per_sample ? B : 1) * N * Dh;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int64_t t = i;
     const int64_t pr = t % np; t /= np;
@@ -577,8 +579,8 @@ __global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const floa
     const int64_t b = t / N;
     const int64_t d = pr * 2;
     T* px = qkv + ((b * S + prefix + n) * 3 + which) * (H * Dh) + h * Dh;
-    const float* ps = sinT + n * Dh;
-    const float* pc = cosT + n * Dh;
+    const float* ps = sinT + b * tbs + n * Dh;
+    const float* pc = cosT + b * tbs + n * Dh;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const float x1 = to_f<T>(px[d + j]), x2 = to_f<T>(px[d + j + half]);
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const floa
 }
 
 extern "C" int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
-                            int64_t prefix, int inverse, int emulate_bf16, void* stream) {
+                            int64_t prefix, int inverse, int emulate_bf16, int per_sample, void* stream) {
   VITK_REQUIRE(qkv && table, "rope: null pointer");
   VITK_REQUIRE(Dh > 0 && Dh % 4 == 0, "rope: head_dim=%lld must be a multiple of 4", (long long)Dh);
   VITK_REQUIRE(prefix >= 0 && prefix <= S, "rope: prefix=%lld outside [0, %lld]", (long long)prefix, (long long)S);
@@ -607,7 +609,8 @@ extern "C" int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B,
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ew_grid(total)), block(256);
   DISPATCH_DTYPE(dtype, T, {
-    hipLaunchKernelGGL((rope_qk_k<T>), grid, block, 0, st, (T*)qkv, table, B, S, H, Dh, prefix, inverse, emulate_bf16);
+    hipLaunchKernelGGL((rope_qk_k<T>), grid, block, 0, st, (T*)qkv, table, B, S, H, Dh, prefix, inverse, emulate_bf16,
+                       per_sample);
   });
   VITK_LAUNCH_CHECK("rope");
   return 0;

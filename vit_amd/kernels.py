@@ -199,9 +199,11 @@ def rope_qk_(qkv: Tensor, table_f32: Tensor, B: int, S: int, H: int, Dh: int, pr
     lib = L.load()
     L.require_gpu(qkv, table_f32)
     assert qkv.is_contiguous() and table_f32.is_contiguous() and table_f32.dtype == torch.float32
-    assert table_f32.shape == (2, S - prefix, Dh), f"rope table {tuple(table_f32.shape)} vs {(2, S - prefix, Dh)}"
+    per_sample = table_f32.dim() == 4   # [2, B, S - prefix, Dh]: one table per sample
+    want = (2, B, S - prefix, Dh) if per_sample else (2, S - prefix, Dh)
+    assert tuple(table_f32.shape) == want, f"rope table {tuple(table_f32.shape)} vs {want}"
     L.check(lib.vitk_rope_qk(L.ptr(qkv), L.dt(qkv), L.ptr(table_f32), B, S, H, Dh, prefix, int(inverse), int(emulate_bf16),
-                             L.stream()))
+                             int(per_sample), L.stream()))
     return qkv
 
 

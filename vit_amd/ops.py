@@ -188,7 +188,7 @@ class AttentionSublayerFn(torch.autograd.Function):
     """x -> x (+) alpha * gamma * dropout(out_proj(SDPA(rope(qkv_proj(norm(x))))))   (vit/attention.py:163-215)."""
 
     @staticmethod
-    def forward(ctx, x, norm_w, norm_b, w_qkv, b_qkv, w_out, b_out, gamma, rope, keep_idx, opt):
+    def forward(ctx, x, norm_w, norm_b, w_qkv, b_qkv, w_out, b_out, gamma, rope, keep_idx, qn_w, qn_b, kn_w, kn_b, opt):
         L.require_gpu(x, norm_w, w_qkv, w_out)
         B, S, D = x.shape
         Dh = opt["head_dim"]
@@ -209,13 +209,34 @@ class AttentionSublayerFn(torch.autograd.Function):
         wq, bq, wo, bo = _cast(w_qkv, tc), _cast(b_qkv, tc), _cast(w_out, tc), _cast(b_out, tc)
         qkv = torch.empty((M, 3 * D), dtype=tc, device=x.device)
         K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv")
-        table, emu = None, False
+        # per-head q/k normalisation over Dh, before RoPE (vit/attention.py:25-41, :95-105).  The heads of q (and of k)
+        # are copied out as a contiguous [M*H, Dh] matrix, which is what the row-norm kernels take and what their
+        # backward needs; the normalised rows go back into the packed buffer.
+        qk_saved = (None,) * 6
+        if qn_w is not None:
+            qk_saved = []
+            for which, (w_, b_) in enumerate(((qn_w, qn_b), (kn_w, kn_b))):
+                pre = qkv[:, which * D:(which + 1) * D].contiguous().view(M * H, Dh)
+                nrm, r_, m_ = K.norm_fwd(pre, w_.detach(), None if b_ is None else b_.detach(), opt["qk_eps"],
+                                         opt["qk_layernorm"], tc)
+                qkv[:, which * D:(which + 1) * D].copy_(nrm.view(M, D))
+                qk_saved += [pre, r_, m_]
+        table, emu, per_sample = None, False, False
         if rope is not None:
-            if rope.dim() != 3:
-                raise NotImplementedError("vit_amd: per-sample (masked) RoPE tables are not supported yet")
             emu = rope.dtype == torch.bfloat16 and tc == torch.bfloat16
-            table = rope.detach().to(torch.float32).contiguous()
-            K.rope_qk_(qkv, table, Bk, S, H, Dh, S - table.shape[1], False, emu)
+            if rope.dim() == 5:   # [2, B, 1, N', Dh]: one table per sample (masked tokens, vit/vit.py:522-527)
+                per_sample = True
+                table = rope.detach()[:, :, 0].to(torch.float32)
+                if keep_idx is not None:   # vit/transformer.py:41-46
+                    table = table.index_select(1, keep_idx)
+                table = table.contiguous()
+                if table.shape[1] != Bk:
+                    raise ValueError(f"vit_amd: RoPE table for {table.shape[1]} samples, batch is {Bk}")
+            elif rope.dim() == 3:
+                table = rope.detach().to(torch.float32).contiguous()
+            else:
+                raise ValueError(f"vit_amd: RoPE table must be [2, N, Dh] or [2, B, 1, N, Dh], got {tuple(rope.shape)}")
+            K.rope_qk_(qkv, table, Bk, S, H, Dh, S - table.shape[-2], False, emu)
         seed_a = next_seed(x.device) if p_attn > 0 else 0
         o, lse = K.attn_fwd(qkv, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
         seed_h = next_seed(x.device) if p_hid > 0 else 0
@@ -227,16 +248,17 @@ class AttentionSublayerFn(torch.autograd.Function):
             zero = torch.zeros((M, D), dtype=tc, device=x.device)
             out, aux = _residual_gemm(o, wo, bo, zero, None, None, 1.0, p_hid, seed_h, want_aux=False)
             y = out.view(Bk, S, D)
-        ctx.save_for_backward(x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows)
+        ctx.save_for_backward(x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows, qn_w, kn_w, *qk_saved)
         ctx.meta = (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, x.dtype, w_qkv.dtype,
-                    norm_b is not None, b_qkv is not None, b_out is not None)
+                    norm_b is not None, b_qkv is not None, b_out is not None, qn_b is not None, kn_b is not None)
         return y
 
     @staticmethod
     def backward(ctx, dnew):
-        x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows = ctx.saved_tensors
+        (x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows, qn_w, kn_w, pre_q, rstd_q, mean_q, pre_k,
+         rstd_k, mean_k) = ctx.saved_tensors
         (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, xdtype, wdtype, has_nb, has_bq,
-         has_bo) = ctx.meta
+         has_bo, has_qnb, has_knb) = ctx.meta
         need = ctx.needs_input_grad
         M = Bk * S
         residual = opt["residual"]
@@ -246,7 +268,17 @@ class AttentionSublayerFn(torch.autograd.Function):
         do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[5], has_bo and need[6], wdtype, tag="out")
         dqkv = K.attn_bwd(qkv, o, lse, do, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
         if table is not None:
-            K.rope_qk_(dqkv, table, Bk, S, H, Dh, S - table.shape[1], True, emu)
+            K.rope_qk_(dqkv, table, Bk, S, H, Dh, S - table.shape[-2], True, emu)
+        dqn = [None, None, None, None]   # d q_norm.weight, d q_norm.bias, d k_norm.weight, d k_norm.bias
+        if qn_w is not None:
+            for which, (w_, pre, r_, m_, has_b) in enumerate(((qn_w, pre_q, rstd_q, mean_q, has_qnb),
+                                                              (kn_w, pre_k, rstd_k, mean_k, has_knb))):
+                dpost = dqkv[:, which * D:(which + 1) * D].contiguous().view(M * H, Dh)
+                dpre = torch.empty_like(dpost)
+                dw_, db_ = K.norm_bwd(dpost, pre, w_.detach(), r_, m_, opt["qk_layernorm"], None, dpre, need[10 + 2 * which],
+                                      has_b and need[11 + 2 * which])
+                dqkv[:, which * D:(which + 1) * D].copy_(dpre.view(M, D))
+                dqn[2 * which], dqn[2 * which + 1] = dw_, db_
         dxn, dwq, dbq = _linear_bwd(dqkv, xn, wq, True, need[3], has_bq and need[4], wdtype, tag="qkv")
         if residual:
             if rows is None:
@@ -264,7 +296,7 @@ class AttentionSublayerFn(torch.autograd.Function):
             dx = dx.to(xdtype)
         if dgamma is not None and dgamma.dtype != g.dtype:
             dgamma = dgamma.to(g.dtype)
-        return (dx if need[0] else None, dnw, dnb, dwq, dbq, dwo, dbo, dgamma, None, None, None)
+        return (dx if need[0] else None, dnw, dnb, dwq, dbq, dwo, dbo, dgamma, None, None, *dqn, None)
 
 
 class MlpSublayerFn(torch.autograd.Function):

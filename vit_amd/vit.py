@@ -1,7 +1,8 @@
 """The ViT encoder (reference: vit/vit.py:254-615): same constructor, attribute tree, state_dict keys and
 forward signature; every arithmetic step of forward/backward runs in libvitk kernels.
 
-Not provided (outside the encoder hot path): heads, decoder / cross-attention factories, token masks,
+Token masks (masked pre-training) drop tokens ahead of the blocks and give every sample its own RoPE rows.
+Not provided (outside the encoder hot path): heads, decoder / cross-attention factories,
 attention-weight visualisation, torchao quantization.  They raise NotImplementedError rather than fall back."""
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ from .initialization import trunc_normal_
 from .norm import make_norm
 from .patch_embed import PatchEmbed2d
 from .rope import RopePositionEmbedding
+from .tokens import apply_mask, create_mask
 from .transformer import TransformerEncoderLayer
 
 __all__ = ["ViT", "ViTConfig", "ViTFeatures"]
@@ -84,8 +86,11 @@ class ViT(nn.Module):
         if any(c is not None for c in configs):
             raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
 
-    def create_mask(self, *args, **kwargs):
-        raise NotImplementedError("vit_amd: token masking is not on the encoder hot path yet")
+    def create_mask(self, input: Tensor, unmasked_ratio: float, scale: int, roll: bool = False) -> Tensor:
+        """Random token mask [B, L] for a raw (un-tokenized) input; True = kept (vit/vit.py:458-494)."""
+        grid = self.stem.tokenized_size(tuple(input.shape[2:]))
+        return create_mask(grid, mask_ratio=1 - unmasked_ratio, batch_size=input.shape[0], scale=scale, roll=roll,
+                           device=input.device)
 
     @property
     def prefix_length(self) -> int:
@@ -102,23 +107,27 @@ class ViT(nn.Module):
             raise ValueError("RoPE is not enabled")
         if len(tokenized_size) != 2:
             raise ValueError(f"RoPE not supported for non-2D input, got {tokenized_size}")
-        if mask is not None:
-            raise NotImplementedError("vit_amd: token masking is not on the encoder hot path yet")
-        return self.rope(H=tokenized_size[0], W=tokenized_size[1], rope_seed=rope_seed)
+        rope = self.rope(H=tokenized_size[0], W=tokenized_size[1], rope_seed=rope_seed)
+        if mask is not None:   # every sample keeps its own rows of the table: [2, B, 1, N', Dh] (vit/vit.py:522-527)
+            B = mask.shape[0]
+            sin = apply_mask(mask, rope[0][None].expand(B, -1, -1))
+            cos = apply_mask(mask, rope[1][None].expand(B, -1, -1))
+            rope = torch.stack([sin[:, None], cos[:, None]], dim=0)
+        return rope
 
     def normalize_patch_embeddings(self, x: Tensor) -> Tensor:
         return x if self.patch_embed_norm is None else self.patch_embed_norm(x)
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, rope_seed: Optional[int] = None,
                 output_norm: bool = True) -> ViTFeatures:
-        if mask is not None:
-            raise NotImplementedError("vit_amd: token masking is not on the encoder hot path yet")
         c = self._config
         grid = self.stem.tokenized_size(x.shape[2:])
         x = self.stem(x)
         x = self.normalize_patch_embeddings(x)
+        if mask is not None:   # dropped tokens leave the sequence before the blocks (vit/vit.py:545)
+            x = apply_mask(mask, x)
         x = self.add_prefix_tokens(x)
-        rope = self.prepare_rope(grid, None, rope_seed) if self.rope is not None else None
+        rope = self.prepare_rope(grid, mask, rope_seed) if self.rope is not None else None
         for block in self.blocks:
             assert isinstance(block, TransformerEncoderLayer)
             if c.activation_checkpointing and self.training:

@@ -115,7 +115,10 @@ int vitk_gemm(const VitkGemm* g, void* stream);
  *      the strides -------------------------------------------------------------------------------
  * q,k,v,o (and dq,dk,dv,do) are addressed as ptr[b*sb + h*sh + s*ss + d], d contiguous; this lets the
  * kernels read the packed [B,S,3,H,Dh] projection output and write [B,S,H*Dh] directly.
- * lse [B,H,S] fp32 = log-sum-exp of the scaled scores (saved for backward). delta [B,H,S] fp32 scratch. */
+ * lse [B,H,S] fp32 = log-sum-exp of the scaled scores (saved for backward). delta [B,H,S] fp32 scratch.
+ * Cross-attention (CrossAttention / AttentivePool, vit/attention.py:218-280, :594-667): Sk > 0 keys per sample
+ * with their own strides kv_* (k, v) and dkv_* (dk, dv); S then counts the queries.  Sk = 0 is self-attention
+ * (keys = queries, k/v/dk/dv use the q and dq strides).  Cross-attention runs on the portable kernels. */
 typedef struct VitkAttn {
   const void* q; const void* k; const void* v; void* o;
   const void* dout; void* dq; void* dk; void* dv;   /* backward only */
@@ -129,6 +132,9 @@ typedef struct VitkAttn {
   float drop_p;
   int32_t dtype;
   int32_t algo;                 /* 0 auto, 1 portable, 2 MFMA */
+  int64_t Sk;                   /* 0 = self-attention */
+  int64_t kv_sb, kv_sh, kv_ss;     /* strides of k/v when Sk > 0 */
+  int64_t dkv_sb, dkv_sh, dkv_ss;  /* strides of dk/dv when Sk > 0 */
 } VitkAttn;
 
 int vitk_attn_fwd(const VitkAttn* a, void* stream);

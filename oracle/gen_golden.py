@@ -159,6 +159,52 @@ def make_op_level(ref):
     print(f"{'g07_ops':45s} bytes={os.path.getsize(path)}")
 
 
+HEAD_CASES = {
+    # name -> (backbone overrides, mode)
+    "g12_heads_fp32": (dict(activation="swiglu", pos_enc="fourier", num_register_tokens=2), "fp32"),
+    "g12_heads_qknorm_layernorm_fp32": (dict(activation="srelu", pos_enc="rope", qk_normalization=True, norm_type="layernorm",
+                                             attention_bias=True), "fp32"),
+    "g12_heads_autocast": (dict(activation="swiglu", pos_enc="fourier", num_register_tokens=2), "autocast_bf16"),
+}
+
+
+def make_heads(ref, name, overrides, mode, seed):
+    """Encoder + the README's heads (vit/head.py): AttentivePoolHead with 1 and with 3 queries on the visual tokens,
+    the linear Head on the register/cls-free mean.  Fixture: state, x, the three head outputs, x_grad, grads of the
+    loss sum(out.float().square().mean())."""
+    from vit.head import AttentivePoolHeadConfig, HeadConfig
+
+    kw = dict(BASE)
+    kw.update(overrides)
+    kw["dtype"] = torch.float32
+    kw["heads"] = {"pool": AttentivePoolHeadConfig(out_features=10), "pool3": AttentivePoolHeadConfig(out_features=6, num_queries=3),
+                   "lin": HeadConfig(out_features=5)}
+    cfg = ref.ViTConfig(**kw)
+    torch.manual_seed(seed)
+    model = cfg.instantiate()
+    gen = torch.Generator().manual_seed(seed + 17)
+    perturb(model, gen)
+    x = torch.randn(2, cfg.in_channels, 32, 32, generator=gen)
+    ac = torch.autocast("cpu", dtype=torch.bfloat16, enabled=(mode == "autocast_bf16"))
+    model.eval()
+    xg = x.clone().requires_grad_(True)
+    with ac:
+        feats = model(xg)
+        tokens = feats.visual_tokens
+        outs = {"pool": model.heads["pool"](tokens), "pool3": model.heads["pool3"](tokens),
+                "lin": model.heads["lin"](tokens.mean(dim=1))}
+    sum(o.float().square().mean() for o in outs.values()).backward()
+    d = plain_cfg(cfg)
+    d["heads"] = {"pool": dict(out_features=10, num_queries=1), "pool3": dict(out_features=6, num_queries=3),
+                  "lin": dict(out_features=5)}
+    fix = {"cfg": d, "mode": mode, "state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "x": x,
+           "outs": {k: v.detach().clone() for k, v in outs.items()}, "x_grad": xg.grad.clone(),
+           "grads": {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}}
+    path = os.path.join(OUT, name + ".pt")
+    torch.save(fix, path)
+    print(f"{name:45s} outs={[tuple(v.shape) for v in outs.values()]} bytes={os.path.getsize(path)}")
+
+
 def main():
     ref = refshim.import_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -170,6 +216,10 @@ def main():
         make(ref, name, ov, B, hw, mode, seed=1000 + i)
     if not only or any("g07_ops".startswith(p) for p in only):
         make_op_level(ref)
+    for i, (name, (ov, mode)) in enumerate(HEAD_CASES.items()):
+        if only and not any(name.startswith(p) for p in only):
+            continue
+        make_heads(ref, name, ov, mode, seed=2000 + i)
 
 
 if __name__ == "__main__":

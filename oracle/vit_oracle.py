@@ -327,6 +327,48 @@ def vit_forward(cfg: OracleConfig, sd: dict, x: Tensor, *, training: bool = Fals
 
 
 # --------------------------------------------------------------------------------------------
+# heads (vit/head.py, vit/attention.py:112-162, :218-280, :594-667)
+# --------------------------------------------------------------------------------------------
+def cross_attention(cfg: OracleConfig, sd: dict, pre: str, q: Tensor, kv: Tensor, num_heads: int, training: bool = False,
+                    attention_dropout: float = 0.0, hidden_dropout: float = 0.0) -> Tensor:
+    """attention_q_kv_packed, vit/attention.py:218-280: norm on the query side only, no RoPE."""
+    ln = cfg.norm_type == "layernorm"
+    D = q.shape[-1]
+    dh = D // num_heads
+    qn = apply_norm(q, sd[pre + "norm.weight"], sd.get(pre + "norm.bias"), 1e-5, ln)
+    qp = F.linear(qn, sd[pre + "q_proj.weight"], sd.get(pre + "q_proj.bias"))
+    k, v = F.linear(kv, sd[pre + "kv_proj.weight"], sd.get(pre + "kv_proj.bias")).chunk(2, dim=-1)
+    B, Lq, _ = qp.shape
+    Lk = k.shape[1]
+    qp = qp.view(B, Lq, -1, dh).transpose(1, 2)
+    k = k.view(B, Lk, -1, dh).transpose(1, 2)
+    v = v.view(B, Lk, -1, dh).transpose(1, 2)
+    if cfg.qk_normalization:
+        qp = apply_norm(qp, sd[pre + "q_norm.weight"], sd.get(pre + "q_norm.bias"), 1e-5, ln)
+        k = apply_norm(k, sd[pre + "k_norm.weight"], sd.get(pre + "k_norm.bias"), 1e-5, ln)
+    o = F.scaled_dot_product_attention(qp, k, v, attn_mask=None, dropout_p=attention_dropout if training else 0.0,
+                                       is_causal=False, enable_gqa=True)
+    o = o.transpose(1, 2).reshape(B, Lq, D)
+    o = F.linear(o, sd[pre + "out_proj.weight"], sd.get(pre + "out_proj.bias"))
+    return F.dropout(o, p=hidden_dropout, training=training)
+
+
+def attentive_pool_head(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, num_heads: int) -> Tensor:
+    """AttentivePoolHead.forward, vit/head.py:247-248 with AttentivePool.forward vit/attention.py:648-652 and
+    Head.forward vit/head.py:204-206 (dropout probabilities 0)."""
+    query = sd[pre + "pool.query"].expand(x.shape[0], -1, -1)
+    y = cross_attention(cfg, sd, pre + "pool.cross_attention.", query, x, num_heads)
+    if y.shape[1] == 1:
+        y = y.squeeze(1)
+    return F.linear(y, sd[pre + "proj.proj.weight"], sd.get(pre + "proj.proj.bias"))
+
+
+def linear_head(sd: dict, pre: str, x: Tensor) -> Tensor:
+    """Head.forward, vit/head.py:204-206."""
+    return F.linear(x, sd[pre + "proj.weight"], sd.get(pre + "proj.bias"))
+
+
+# --------------------------------------------------------------------------------------------
 # state construction (used by tests and the CPU baseline; the product has its own initialiser)
 # --------------------------------------------------------------------------------------------
 def init_state(cfg: OracleConfig, seed: int = 0, device=None, perturb_residual_outputs: bool = True) -> dict:

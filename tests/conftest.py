@@ -28,4 +28,9 @@ def load_golden(name: str) -> dict:
 
 
 def golden_names() -> list[str]:
-    return sorted(f[:-3] for f in os.listdir(GOLDEN) if f.endswith(".pt") and f != "g07_ops.pt")
+    """Encoder fixtures (g07_ops holds op-level vectors, g12_* the head fixtures)."""
+    return sorted(f[:-3] for f in os.listdir(GOLDEN) if f.endswith(".pt") and f != "g07_ops.pt" and not f.startswith("g12_"))
+
+
+def head_golden_names() -> list[str]:
+    return sorted(f[:-3] for f in os.listdir(GOLDEN) if f.endswith(".pt") and f.startswith("g12_"))

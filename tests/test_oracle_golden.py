@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from conftest import golden_names, load_golden
+from conftest import golden_names, head_golden_names, load_golden
 from oracle import vit_oracle as O
 
 DT = {"float32": torch.float32, "bfloat16": torch.bfloat16}
@@ -40,6 +40,40 @@ def test_oracle_matches_reference_fixture(name):
     assert set(r["grads"]) == set(fix["grads"])
     for k, g in fix["grads"].items():
         torch.testing.assert_close(r["grads"][k], g, **tol(fix["mode"]), msg=lambda m, k=k: f"{k}: {m}")
+
+
+def oracle_heads(cfg, sd, x, num_heads):
+    """Encoder, then the three heads of the g12 fixtures (see oracle/gen_golden.py: make_heads)."""
+    feats = O.vit_forward(cfg, sd, x, training=False)
+    tokens = feats[:, cfg.num_cls_tokens + cfg.num_register_tokens:]
+    return {"pool": O.attentive_pool_head(cfg, sd, "heads.pool.", tokens, num_heads),
+            "pool3": O.attentive_pool_head(cfg, sd, "heads.pool3.", tokens, num_heads),
+            "lin": O.linear_head(sd, "heads.lin.", tokens.mean(dim=1))}
+
+
+@pytest.mark.parametrize("name", head_golden_names())
+def test_oracle_heads_match_reference_fixture(name):
+    fix = load_golden(name)
+    kw = dict(fix["cfg"])
+    kw.pop("heads")
+    kw["dtype"] = DT[kw["dtype"]]
+    cfg = O.OracleConfig(**kw)
+    torch.set_num_threads(1)
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k != "rope.periods" and v.numel() > 0)
+              for k, v in fix["state"].items()}
+    x = fix["x"].clone().requires_grad_(True)
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=fix["mode"] == "autocast_bf16"):
+        outs = oracle_heads(cfg, params, x, cfg.num_attention_heads)
+    sum(o.float().square().mean() for o in outs.values()).backward()
+    t = tol(fix["mode"])
+    for k, v in fix["outs"].items():
+        assert outs[k].dtype == v.dtype and outs[k].shape == v.shape
+        torch.testing.assert_close(outs[k].detach(), v, **t, msg=lambda m, k=k: f"{k}: {m}")
+    torch.testing.assert_close(x.grad, fix["x_grad"], **t)
+    got = {k: p.grad for k, p in params.items() if p.requires_grad and p.grad is not None}
+    assert set(got) == set(fix["grads"])
+    for k, g in fix["grads"].items():
+        torch.testing.assert_close(got[k], g, **t, msg=lambda m, k=k: f"{k}: {m}")
 
 
 def test_op_level_vectors():

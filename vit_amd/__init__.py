@@ -7,7 +7,8 @@
 Importing the package does not load the extension; the first kernel call does, and raises if it is missing."""
 from .config import ViTConfig
 from .features import ViTFeatures
+from .head import AttentivePoolHead, AttentivePoolHeadConfig, Head, HeadConfig
 from .vit import ViT
 
-__all__ = ["ViT", "ViTConfig", "ViTFeatures"]
+__all__ = ["ViT", "ViTConfig", "ViTFeatures", "Head", "HeadConfig", "AttentivePoolHead", "AttentivePoolHeadConfig"]
 __version__ = "0.1.0"

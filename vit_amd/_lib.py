@@ -49,6 +49,8 @@ class VitkAttn(C.Structure):
         ("dq_sb", C.c_int64), ("dq_sh", C.c_int64), ("dq_ss", C.c_int64),
         ("seed", C.c_uint64), ("scale", C.c_float), ("drop_p", C.c_float),
         ("dtype", C.c_int32), ("algo", C.c_int32),
+        ("Sk", C.c_int64), ("kv_sb", C.c_int64), ("kv_sh", C.c_int64), ("kv_ss", C.c_int64),
+        ("dkv_sb", C.c_int64), ("dkv_sh", C.c_int64), ("dkv_ss", C.c_int64),
     ]
 
 

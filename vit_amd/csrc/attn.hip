@@ -23,6 +23,9 @@ struct AttnP {
   float *lse, *delta;
   int64_t B, H, S, Dh;
   int64_t q_sb, q_sh, q_ss, o_sb, o_sh, o_ss, g_sb, g_sh, g_ss;
+  // cross-attention (portable kernels only): Sk keys per sample, strides of k/v and of dk/dv.  Self-attention: Sk = S
+  // and the strides repeat those of q and dq.
+  int64_t Sk, k_sb, k_sh, k_ss, gk_sb, gk_sh, gk_ss;
   uint64_t seed;
   float scale, keep_scale;
   uint32_t thr;
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_k(AttnP p) {
   float* Ks = sm;
   float* Vs = sm + PT * Dh;
   const T* qp = (const T*)p.q + b * p.q_sb + h * p.q_sh;
-  const T* kp = (const T*)p.k + b * p.q_sb + h * p.q_sh;
-  const T* vp = (const T*)p.v + b * p.q_sb + h * p.q_sh;
+  const T* kp = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* vp = (const T*)p.v + b * p.k_sb + h * p.k_sh;
   const bool qv = qrow < p.S;
   float q[PMAXI], o[PMAXI];
 #pragma unroll
@@ -84,13 +87,13 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_k(AttnP p) {
     o[i] = 0.f;
   }
   float m = -INFINITY, l = 0.f;
-  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.S;
-  for (int64_t k0 = 0; k0 < p.S; k0 += PT) {
+  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.Sk;
+  for (int64_t k0 = 0; k0 < p.Sk; k0 += PT) {
     __syncthreads();
-    pload_tile<T>(Ks, kp, p.q_ss, k0, p.S, Dh, tid);
-    pload_tile<T>(Vs, vp, p.q_ss, k0, p.S, Dh, tid);
+    pload_tile<T>(Ks, kp, p.k_ss, k0, p.Sk, Dh, tid);
+    pload_tile<T>(Vs, vp, p.k_ss, k0, p.Sk, Dh, tid);
     __syncthreads();
-    const int nk = (int)(p.S - k0 < PT ? p.S - k0 : PT);
+    const int nk = (int)(p.Sk - k0 < PT ? p.Sk - k0 : PT);
     for (int kk = 0; kk < nk; kk++) {
       float s = 0.f;
 #pragma unroll
@@ -131,8 +134,8 @@ __global__ __launch_bounds__(256) void attn_dq_simple_k(AttnP p) {
   float* Ks = sm;
   float* Vs = sm + PT * Dh;
   const T* qp = (const T*)p.q + b * p.q_sb + h * p.q_sh;
-  const T* kp = (const T*)p.k + b * p.q_sb + h * p.q_sh;
-  const T* vp = (const T*)p.v + b * p.q_sb + h * p.q_sh;
+  const T* kp = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* vp = (const T*)p.v + b * p.k_sb + h * p.k_sh;
   const T* gp = (const T*)p.dout + b * p.o_sb + h * p.o_sh;
   const bool qv = qrow < p.S;
   float q[PMAXI], g[PMAXI], dq[PMAXI];
@@ -145,13 +148,13 @@ __global__ __launch_bounds__(256) void attn_dq_simple_k(AttnP p) {
   }
   const int64_t srow = (b * p.H + h) * p.S + qrow;
   const float lse = qv ? p.lse[srow] : 0.f, delta = qv ? p.delta[srow] : 0.f;
-  const uint64_t rbase = (uint64_t)srow * p.S;
-  for (int64_t k0 = 0; k0 < p.S; k0 += PT) {
+  const uint64_t rbase = (uint64_t)srow * p.Sk;
+  for (int64_t k0 = 0; k0 < p.Sk; k0 += PT) {
     __syncthreads();
-    pload_tile<T>(Ks, kp, p.q_ss, k0, p.S, Dh, tid);
-    pload_tile<T>(Vs, vp, p.q_ss, k0, p.S, Dh, tid);
+    pload_tile<T>(Ks, kp, p.k_ss, k0, p.Sk, Dh, tid);
+    pload_tile<T>(Vs, vp, p.k_ss, k0, p.Sk, Dh, tid);
     __syncthreads();
-    const int nk = (int)(p.S - k0 < PT ? p.S - k0 : PT);
+    const int nk = (int)(p.Sk - k0 < PT ? p.Sk - k0 : PT);
     for (int kk = 0; kk < nk; kk++) {
       float s = 0.f, dp = 0.f;
 #pragma unroll
@@ -189,16 +192,16 @@ __global__ __launch_bounds__(256) void attn_dkdv_simple_k(AttnP p) {
   float* Gs = sm + PT * Dh;
   float* Ls = sm + 2 * PT * Dh;  // lse[PT], delta[PT]
   const T* qp = (const T*)p.q + b * p.q_sb + h * p.q_sh;
-  const T* kp = (const T*)p.k + b * p.q_sb + h * p.q_sh;
-  const T* vp = (const T*)p.v + b * p.q_sb + h * p.q_sh;
+  const T* kp = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* vp = (const T*)p.v + b * p.k_sb + h * p.k_sh;
   const T* gp = (const T*)p.dout + b * p.o_sb + h * p.o_sh;
-  const bool kv = krow < p.S;
+  const bool kv = krow < p.Sk;
   float k[PMAXI], v[PMAXI], dk[PMAXI], dv[PMAXI];
 #pragma unroll
   for (int i = 0; i < PMAXI; i++) {
     const int d = part + 4 * i;
-    k[i] = (kv && d < Dh) ? to_f<T>(kp[krow * p.q_ss + d]) : 0.f;
-    v[i] = (kv && d < Dh) ? to_f<T>(vp[krow * p.q_ss + d]) : 0.f;
+    k[i] = (kv && d < Dh) ? to_f<T>(kp[krow * p.k_ss + d]) : 0.f;
+    v[i] = (kv && d < Dh) ? to_f<T>(vp[krow * p.k_ss + d]) : 0.f;
     dk[i] = 0.f; dv[i] = 0.f;
   }
   const int64_t sbase = (b * p.H + h) * p.S;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_simple_k(AttnP p) {
       const float pr = expf(s - Ls[qq]);
       float pd = pr;
       if (p.thr) {
-        const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + qq) * p.S + (uint64_t)krow) >= p.thr;
+        const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + qq) * p.Sk + (uint64_t)krow) >= p.thr;
         pd = keep ? pr * p.keep_scale : 0.f;
         dp = keep ? dp * p.keep_scale : 0.f;
       }
@@ -238,8 +241,8 @@ __global__ __launch_bounds__(256) void attn_dkdv_simple_k(AttnP p) {
     }
   }
   if (!kv) return;
-  T* okp = (T*)p.dk + b * p.g_sb + h * p.g_sh + krow * p.g_ss;
-  T* ovp = (T*)p.dv + b * p.g_sb + h * p.g_sh + krow * p.g_ss;
+  T* okp = (T*)p.dk + b * p.gk_sb + h * p.gk_sh + krow * p.gk_ss;
+  T* ovp = (T*)p.dv + b * p.gk_sb + h * p.gk_sh + krow * p.gk_ss;
 #pragma unroll
   for (int i = 0; i < PMAXI; i++) {
     const int d = part + 4 * i;
@@ -814,6 +817,10 @@ static AttnP make_p(const VitkAttn* a) {
   p.lse = a->lse; p.delta = a->delta; p.B = a->B; p.H = a->H; p.S = a->S; p.Dh = a->Dh;
   p.q_sb = a->q_sb; p.q_sh = a->q_sh; p.q_ss = a->q_ss; p.o_sb = a->o_sb; p.o_sh = a->o_sh; p.o_ss = a->o_ss;
   p.g_sb = a->dq_sb; p.g_sh = a->dq_sh; p.g_ss = a->dq_ss;
+  const bool cross = a->Sk > 0;
+  p.Sk = cross ? a->Sk : a->S;
+  p.k_sb = cross ? a->kv_sb : a->q_sb; p.k_sh = cross ? a->kv_sh : a->q_sh; p.k_ss = cross ? a->kv_ss : a->q_ss;
+  p.gk_sb = cross ? a->dkv_sb : a->dq_sb; p.gk_sh = cross ? a->dkv_sh : a->dq_sh; p.gk_ss = cross ? a->dkv_ss : a->dq_ss;
   p.seed = a->seed; p.scale = a->scale;
   p.thr = a->drop_p > 0.f ? drop_threshold(a->drop_p) : 0;
   p.keep_scale = 1.f / (1.f - a->drop_p);
@@ -821,6 +828,7 @@ static AttnP make_p(const VitkAttn* a) {
 }
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool attn_mfma_ok(const VitkAttn* a, bool bwd) {
+  if (a->Sk > 0) return false;   // cross-attention (its own key count and k/v strides) runs on the portable kernels
   if (a->dtype != VITK_BF16 || a->Dh % 8 || a->Dh > 128 || a->Dh < 8) return false;
   const int64_t st[] = {a->q_sb, a->q_sh, a->q_ss, a->o_sb, a->o_sh, a->o_ss};
   for (int64_t s : st) if (s % 8) return false;
@@ -839,6 +847,7 @@ static int attn_validate(const VitkAttn* a, bool bwd) {
   VITK_REQUIRE(a->B >= 0 && a->H > 0 && a->S > 0 && a->Dh > 0 && a->Dh <= 128, "attn: bad shape B=%lld H=%lld S=%lld Dh=%lld",
                (long long)a->B, (long long)a->H, (long long)a->S, (long long)a->Dh);
   VITK_REQUIRE(a->H <= 65535 && a->B <= 65535, "attn: B and H must be <= 65535");
+  VITK_REQUIRE(a->Sk >= 0, "attn: Sk=%lld must be 0 (self-attention) or the number of keys", (long long)a->Sk);
   VITK_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f, "attn: dropout p=%f out of range", a->drop_p);
   VITK_REQUIRE(a->dtype == VITK_F32 || a->dtype == VITK_BF16, "attn: bad dtype");
   if (bwd) VITK_REQUIRE(a->dout && a->dq && a->dk && a->dv && a->delta, "attn_bwd: null pointer");
@@ -916,13 +925,14 @@ extern "C" int vitk_attn_bwd(const VitkAttn* a, void* stream) {
     if (a->dtype == VITK_F32) hipLaunchKernelGGL((attn_delta_k<float>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_delta_k<bf16>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);
     dim3 grid((unsigned)ceil_div(a->S, 64), (unsigned)a->H, (unsigned)a->B);
+    dim3 gridk((unsigned)ceil_div(p.Sk, 64), (unsigned)a->H, (unsigned)a->B);
     const size_t lds = (size_t)2 * PT * a->Dh * sizeof(float);
     if (a->dtype == VITK_F32) {
       hipLaunchKernelGGL((attn_dq_simple_k<float>), grid, dim3(256), lds, st, p);
-      hipLaunchKernelGGL((attn_dkdv_simple_k<float>), grid, dim3(256), lds + 512, st, p);
+      hipLaunchKernelGGL((attn_dkdv_simple_k<float>), gridk, dim3(256), lds + 512, st, p);
     } else {
       hipLaunchKernelGGL((attn_dq_simple_k<bf16>), grid, dim3(256), lds, st, p);
-      hipLaunchKernelGGL((attn_dkdv_simple_k<bf16>), grid, dim3(256), lds + 512, st, p);
+      hipLaunchKernelGGL((attn_dkdv_simple_k<bf16>), gridk, dim3(256), lds + 512, st, p);
     }
   }
   VITK_LAUNCH_CHECK("attn_bwd");

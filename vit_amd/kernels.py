@@ -194,6 +194,56 @@ def attn_bwd(qkv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, S: int, 
     return dqkv
 
 
+def _cross_desc(q: Tensor, kv: Tensor, o: Tensor, lse: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: int, scale: float,
+                drop_p: float, seed: int) -> L.VitkAttn:
+    """q [B*Sq, H*Dh]; kv [B*Sk, 2*H*Dh] = [k | v]; o [B*Sq, H*Dh]."""
+    D = H * Dh
+    a = L.VitkAttn()
+    a.q, a.k, a.v = q.data_ptr(), kv.data_ptr(), kv.data_ptr() + D * kv.element_size()
+    a.o, a.lse = L.ptr(o), L.ptr(lse)
+    a.B, a.H, a.S, a.Dh, a.Sk = B, H, Sq, Dh, Sk
+    a.q_sb, a.q_sh, a.q_ss = Sq * D, Dh, D
+    a.kv_sb, a.kv_sh, a.kv_ss = Sk * 2 * D, Dh, 2 * D
+    a.o_sb, a.o_sh, a.o_ss = Sq * D, Dh, D
+    a.seed, a.scale, a.drop_p = seed & 0xFFFFFFFFFFFFFFFF, scale, drop_p
+    a.dtype = L.dt(q)
+    a.algo = 0
+    return a
+
+
+def attn_cross_fwd(q: Tensor, kv: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: int, scale: float, drop_p: float = 0.0,
+                   seed: int = 0):
+    """Attention of Sq queries over Sk keys per sample (vit/attention.py:269-273 with Lq != Lk)."""
+    lib = L.load()
+    L.require_gpu(q, kv)
+    D = H * Dh
+    assert q.is_contiguous() and kv.is_contiguous() and q.shape == (B * Sq, D) and kv.shape == (B * Sk, 2 * D)
+    assert q.dtype == kv.dtype
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    a = _cross_desc(q, kv, o, lse, B, Sq, Sk, H, Dh, scale, drop_p, seed)
+    L.check(lib.vitk_attn_fwd(C.byref(a), L.stream()))
+    return o, lse
+
+
+def attn_cross_bwd(q: Tensor, kv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: int,
+                   scale: float, drop_p: float = 0.0, seed: int = 0):
+    """Returns (dq [B*Sq, D], dkv [B*Sk, 2D])."""
+    lib = L.load()
+    L.require_gpu(q, kv, o, lse, dout)
+    dout = _c(dout)
+    D = H * Dh
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    a = _cross_desc(q, kv, o, lse, B, Sq, Sk, H, Dh, scale, drop_p, seed)
+    a.dout, a.delta = L.ptr(dout), L.ptr(delta)
+    a.dq, a.dk, a.dv = dq.data_ptr(), dkv.data_ptr(), dkv.data_ptr() + D * dkv.element_size()
+    a.dq_sb, a.dq_sh, a.dq_ss = Sq * D, Dh, D
+    a.dkv_sb, a.dkv_sh, a.dkv_ss = Sk * 2 * D, Dh, 2 * D
+    L.check(lib.vitk_attn_bwd(C.byref(a), L.stream()))
+    return dq, dkv
+
+
 def rope_qk_(qkv: Tensor, table_f32: Tensor, B: int, S: int, H: int, Dh: int, prefix: int, inverse: bool,
              emulate_bf16: bool) -> Tensor:
     lib = L.load()

@@ -149,6 +149,31 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# F.dropout on a [..., N] tensor (N % 4 == 0): mask from (seed, element index), regenerated in backward
+# ------------------------------------------------------------------------------------------------
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        L.require_gpu(x)
+        N = x.shape[-1]
+        x2 = x.detach().reshape(-1, N)
+        ctx.p, ctx.seed, ctx.shape = p, seed, x.shape
+        return K.scale_cast(x2, x2.shape[0], N, x.dtype, drop_p=p, seed=seed).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N = ctx.shape[-1]
+        dy2 = dy.reshape(-1, N)
+        return K.scale_cast(dy2, dy2.shape[0], N, dy.dtype, drop_p=ctx.p, seed=ctx.seed).view(ctx.shape), None, None
+
+
+def dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p), next_seed(x.device))
+
+
+# ------------------------------------------------------------------------------------------------
 # residual sub-layers of the encoder block (vit/transformer.py:146-157)
 # ------------------------------------------------------------------------------------------------
 def _residual_dtype(x: Tensor, gamma: Optional[Tensor], tc: torch.dtype) -> torch.dtype:
@@ -297,6 +322,89 @@ class AttentionSublayerFn(torch.autograd.Function):
         if dgamma is not None and dgamma.dtype != g.dtype:
             dgamma = dgamma.to(g.dtype)
         return (dx if need[0] else None, dnw, dnb, dwq, dbq, dwo, dbo, dgamma, None, None, *dqn, None)
+
+
+class CrossAttentionFn(torch.autograd.Function):
+    """dropout(out_proj(SDPA(q_proj(norm(q)), kv_proj(kv))))   (vit/attention.py:112-162, :218-280): Lq queries attend to
+    Lk keys; the norm is on the query side only."""
+
+    @staticmethod
+    def forward(ctx, q, kv, norm_w, norm_b, w_q, b_q, w_kv, b_kv, w_out, b_out, qn_w, qn_b, kn_w, kn_b, opt):
+        L.require_gpu(q, kv, norm_w, w_q, w_kv, w_out)
+        B, Lq, D = q.shape
+        Lk = kv.shape[1]
+        if kv.shape[0] != B or kv.shape[2] != D:
+            raise ValueError(f"vit_amd: q {tuple(q.shape)} and kv {tuple(kv.shape)} do not go together")
+        Dh = opt["head_dim"]
+        H = D // Dh
+        tc = compute_dtype(w_q.dtype)
+        training = opt["training"]
+        p_attn = opt["attention_dropout"] if training else 0.0
+        p_hid = opt["dropout"] if training else 0.0
+        Mq, Mk = B * Lq, B * Lk
+
+        q2 = q.detach().reshape(Mq, D).contiguous()
+        qn, rstd, mean = K.norm_fwd(q2, norm_w.detach(), None if norm_b is None else norm_b.detach(), opt["eps"],
+                                    opt["layernorm"], tc)
+        kv2 = _cast(kv.reshape(Mk, D), tc)
+        wq, bq, wkv, bkv, wo, bo = (_cast(t, tc) for t in (w_q, b_q, w_kv, b_kv, w_out, b_out))
+        qp = torch.empty((Mq, D), dtype=tc, device=q.device)
+        K.gemm(qn, wq, trans_a=False, trans_b=False, M=Mq, N=D, K=D, out=qp, bias=bq)
+        kvp = torch.empty((Mk, 2 * D), dtype=tc, device=q.device)
+        K.gemm(kv2, wkv, trans_a=False, trans_b=False, M=Mk, N=2 * D, K=D, out=kvp, bias=bkv)
+        qk_saved = (None,) * 6
+        if qn_w is not None:   # per-head normalisation of q and k (vit/attention.py:25-41)
+            pre_q = qp.view(Mq * H, Dh)
+            nq, rq, mq = K.norm_fwd(pre_q, qn_w.detach(), None if qn_b is None else qn_b.detach(), opt["qk_eps"],
+                                    opt["qk_layernorm"], tc)
+            qp = nq.view(Mq, D)
+            pre_k = kvp[:, :D].contiguous().view(Mk * H, Dh)
+            nk, rk, mk = K.norm_fwd(pre_k, kn_w.detach(), None if kn_b is None else kn_b.detach(), opt["qk_eps"],
+                                    opt["qk_layernorm"], tc)
+            kvp[:, :D].copy_(nk.view(Mk, D))
+            qk_saved = (pre_q, rq, mq, pre_k, rk, mk)
+        seed_a = next_seed(q.device) if p_attn > 0 else 0
+        o, lse = K.attn_cross_fwd(qp, kvp, B, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
+        seed_h = next_seed(q.device) if p_hid > 0 else 0
+        zero = torch.zeros((Mq, D), dtype=tc, device=q.device)
+        out, _ = _residual_gemm(o, wo, bo, zero, None, None, 1.0, p_hid, seed_h, want_aux=False)
+        ctx.save_for_backward(q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, qn_w, kn_w, *qk_saved)
+        ctx.meta = (B, Lq, Lk, D, H, Dh, tc, p_attn, p_hid, seed_a, seed_h, opt, q.dtype, kv.dtype, w_q.dtype,
+                    norm_b is not None, b_q is not None, b_kv is not None, b_out is not None, qn_b is not None,
+                    kn_b is not None)
+        return out.view(B, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, qn_w, kn_w, pre_q, rstd_q, mean_q, pre_k, rstd_k,
+         mean_k) = ctx.saved_tensors
+        (B, Lq, Lk, D, H, Dh, tc, p_attn, p_hid, seed_a, seed_h, opt, qdtype, kvdtype, wdtype, has_nb, has_bq, has_bkv,
+         has_bo, has_qnb, has_knb) = ctx.meta
+        need = ctx.needs_input_grad
+        Mq, Mk = B * Lq, B * Lk
+        dy, _ = _residual_grad(_cast(dout.reshape(Mq, D), tc), tc, None, None, Mq, 1.0, p_hid, seed_h, None, False)
+        do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[8], has_bo and need[9], wdtype)
+        dqp, dkvp = K.attn_cross_bwd(qp, kvp, o, lse, do, B, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
+        dqn = [None, None, None, None]
+        if qn_w is not None:
+            dpre = torch.empty_like(dqp)
+            dqn[0], dqn[1] = K.norm_bwd(dqp.view(Mq * H, Dh), pre_q, qn_w.detach(), rstd_q, mean_q, opt["qk_layernorm"], None,
+                                        dpre.view(Mq * H, Dh), need[10], has_qnb and need[11])
+            dqp = dpre
+            dk_post = dkvp[:, :D].contiguous().view(Mk * H, Dh)
+            dk_pre = torch.empty_like(dk_post)
+            dqn[2], dqn[3] = K.norm_bwd(dk_post, pre_k, kn_w.detach(), rstd_k, mean_k, opt["qk_layernorm"], None, dk_pre,
+                                        need[12], has_knb and need[13])
+            dkvp[:, :D].copy_(dk_pre.view(Mk, D))
+        dqn_in, dwq, dbq = _linear_bwd(dqp, qn, wq, True, need[4], has_bq and need[5], wdtype)
+        dkv_in, dwkv, dbkv = _linear_bwd(dkvp, kv2, wkv, need[1], need[6], has_bkv and need[7], wdtype)
+        dq_in = torch.empty_like(q2)
+        dnw, dnb = K.norm_bwd(dqn_in, q2, norm_w.detach(), rstd, mean, opt["layernorm"], None, dq_in, need[2],
+                              has_nb and need[3])
+        dq_in = dq_in.view(B, Lq, D)
+        if dkv_in is not None:
+            dkv_in = dkv_in.view(B, Lk, D).to(kvdtype)
+        return (dq_in if need[0] else None, dkv_in, dnw, dnb, dwq, dbq, dwkv, dbkv, dwo, dbo, *dqn, None)
 
 
 class MlpSublayerFn(torch.autograd.Function):

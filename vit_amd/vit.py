@@ -2,7 +2,8 @@
 forward signature; every arithmetic step of forward/backward runs in libvitk kernels.
 
 Token masks (masked pre-training) drop tokens ahead of the blocks and give every sample its own RoPE rows.
-Not provided (outside the encoder hot path): heads, decoder / cross-attention factories,
+Heads: the linear head and the attentive-pool head (vit_amd/head.py).
+Not provided (outside the encoder hot path): dense-prediction heads, decoder layer factories,
 attention-weight visualisation, torchao quantization.  They raise NotImplementedError rather than fall back."""
 from __future__ import annotations
 
@@ -16,6 +17,7 @@ from torch.utils.checkpoint import checkpoint
 from . import ops
 from .config import ViTConfig
 from .features import ViTFeatures
+from .head import AttentivePoolHeadConfig, HeadConfig
 from .initialization import trunc_normal_
 from .norm import make_norm
 from .patch_embed import PatchEmbed2d
@@ -32,8 +34,10 @@ class ViT(nn.Module):
         super().__init__()
         if len(config.patch_size) != 2:
             raise NotImplementedError("vit_amd: only 2-D patch embedding is on the hot path (PatchEmbed3d is not built)")
-        if config.heads:
-            raise NotImplementedError("vit_amd: heads are downstream of the encoder hot path and are not built")
+        for name, head_config in config.heads.items():
+            if not isinstance(head_config, (HeadConfig, AttentivePoolHeadConfig)):
+                raise NotImplementedError(f"vit_amd: head {name!r} ({type(head_config).__name__}) is not built; "
+                                          "HeadConfig and AttentivePoolHeadConfig are")
         if any(c is not None for c in (mlp_quantization_config, qkv_quantization_config, attn_quantization_config)):
             raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
         kw = {"device": device, "dtype": config.dtype}
@@ -58,7 +62,7 @@ class ViT(nn.Module):
         self.output_norm = make_norm(D, config.norm_type, **kw)
         self.mlp_requires_grad_(config.mlp_requires_grad)
         self.self_attention_requires_grad_(config.self_attention_requires_grad)
-        self.heads = nn.ModuleDict()
+        self.heads = nn.ModuleDict({name: self.create_head(name, hc, device=device) for name, hc in config.heads.items()})
 
     # ---- construction helpers ------------------------------------------------------------------
     @property
@@ -76,6 +80,13 @@ class ViT(nn.Module):
             glu_extra_bias=c.glu_extra_bias, mlp_quantization_config=mlp_quantization_config,
             qkv_quantization_config=qkv_quantization_config, attn_quantization_config=attn_quantization_config,
             device=device, dtype=c.dtype if dtype is None else dtype)
+
+    def create_head(self, name: str, head_config: Any, device: Optional[torch.device] = None, dtype=None) -> nn.Module:
+        """vit/vit.py:435-447."""
+        return head_config.instantiate(self._config, device=device, dtype=dtype or self._config.dtype)
+
+    def get_head(self, name: str) -> nn.Module:
+        return self.heads[name]
 
     def get_block(self, i: int) -> TransformerEncoderLayer:
         block = self.blocks[i]

@@ -205,6 +205,47 @@ def make_heads(ref, name, overrides, mode, seed):
     print(f"{name:45s} outs={[tuple(v.shape) for v in outs.values()]} bytes={os.path.getsize(path)}")
 
 
+LAYER_CASES = {
+    # name -> (backbone overrides, mode)
+    "g13_decoder_layers_fp32": (dict(activation="swiglu", pos_enc="fourier", layer_scale=0.5), "fp32"),
+    "g13_decoder_layers_qknorm_ln_fp32": (dict(activation="gelu", pos_enc="fourier", norm_type="layernorm", qk_normalization=True),
+                                          "fp32"),
+    "g13_decoder_layers_autocast": (dict(activation="swiglu", pos_enc="fourier", layer_scale=0.5), "autocast_bf16"),
+}
+
+
+def make_layers(ref, name, overrides, mode, seed):
+    """TransformerDecoderLayer and CrossAttentionTransformer from the backbone's factories (vit/vit.py:373-433),
+    applied to x [3, 7, D] with memory kv [3, 11, D].  Fixture: the two state dicts, inputs, outputs, input and
+    parameter gradients of out.float().square().mean()."""
+    kw = dict(BASE)
+    kw.update(overrides)
+    kw["dtype"] = torch.float32
+    cfg = ref.ViTConfig(**kw)
+    torch.manual_seed(seed)
+    model = cfg.instantiate()
+    gen = torch.Generator().manual_seed(seed + 17)
+    layers = {"decoder": model.create_decoder_layer(), "cross": model.create_cross_attention_layer()}
+    D = cfg.hidden_size
+    x = torch.randn(3, 7, D, generator=gen)
+    kv = torch.randn(3, 11, D, generator=gen)
+    fix = {"cfg": plain_cfg(cfg), "mode": mode, "x": x, "kv": kv}
+    ac = torch.autocast("cpu", dtype=torch.bfloat16, enabled=(mode == "autocast_bf16"))
+    for tag, layer in layers.items():
+        perturb(layer, gen)
+        layer.eval()
+        xg, kvg = x.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        with ac:
+            out = layer(xg, kvg)
+        out.float().square().mean().backward()
+        fix[tag] = {"state": {k: v.detach().clone() for k, v in layer.state_dict().items()}, "out": out.detach().clone(),
+                    "x_grad": xg.grad.clone(), "kv_grad": kvg.grad.clone(),
+                    "grads": {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}}
+    path = os.path.join(OUT, name + ".pt")
+    torch.save(fix, path)
+    print(f"{name:45s} out={tuple(fix['decoder']['out'].shape)} bytes={os.path.getsize(path)}")
+
+
 def main():
     ref = refshim.import_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -220,6 +261,10 @@ def main():
         if only and not any(name.startswith(p) for p in only):
             continue
         make_heads(ref, name, ov, mode, seed=2000 + i)
+    for i, (name, (ov, mode)) in enumerate(LAYER_CASES.items()):
+        if only and not any(name.startswith(p) for p in only):
+            continue
+        make_layers(ref, name, ov, mode, seed=3000 + i)
 
 
 if __name__ == "__main__":

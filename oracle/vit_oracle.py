@@ -353,6 +353,27 @@ def cross_attention(cfg: OracleConfig, sd: dict, pre: str, q: Tensor, kv: Tensor
     return F.dropout(o, p=hidden_dropout, training=training)
 
 
+def decoder_layer(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, kv: Tensor, training: bool, self_attn: bool) -> Tensor:
+    """TransformerDecoderLayer.forward (vit/transformer.py:262-284) when ``self_attn``, else
+    CrossAttentionTransformer.forward (:367-384).  ``pre`` is the prefix of the layer's keys in ``sd``."""
+    def scaled(o, name):
+        return o * sd[pre + name + ".gamma"] if cfg.layer_scale is not None else o
+
+    B = x.shape[0]
+    if self_attn:
+        xr, idx, scale = select_residual_subset(x, cfg.drop_path_rate, training)
+        o = self_attention(cfg, sd, pre + "self_attention.", xr, None, training)
+        x = merge_residual_subset(x, scaled(o, "layer_scale_attn"), idx, scale)
+    xr, idx, scale = select_residual_subset(x, cfg.drop_path_rate, training)
+    kvr = kv if idx is None or kv.shape[0] != B else kv.index_select(0, idx)
+    o = cross_attention(cfg, sd, pre + "cross_attention.", xr, kvr, cfg.num_attention_heads, training,
+                        cfg.attention_dropout, cfg.hidden_dropout)
+    x = merge_residual_subset(x, scaled(o, "layer_scale_cross"), idx, scale)
+    xr, idx, scale = select_residual_subset(x, cfg.drop_path_rate, training)
+    o = norm_mlp(cfg, sd, pre + "mlp.", xr, training)
+    return merge_residual_subset(x, scaled(o, "layer_scale_mlp"), idx, scale)
+
+
 def attentive_pool_head(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, num_heads: int) -> Tensor:
     """AttentivePoolHead.forward, vit/head.py:247-248 with AttentivePool.forward vit/attention.py:648-652 and
     Head.forward vit/head.py:204-206 (dropout probabilities 0)."""

@@ -5,7 +5,7 @@ Tolerances (north-star): fp32 rtol 1e-4, bf16 / autocast rtol 2e-2; absolute flo
 import pytest
 import torch
 
-from conftest import golden_names, head_golden_names, load_golden
+from conftest import golden_names, head_golden_names, layer_golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +120,71 @@ def test_heads_golden_fixture(name):
     for k, g in fix["grads"].items():
         assert grads[k].dtype == g.dtype, k
         close(grads[k], g, grtol, k, atol_scale=2.0)
+
+
+@pytest.mark.parametrize("name", layer_golden_names())
+@pytest.mark.parametrize("kind", ["decoder", "cross"])
+def test_decoder_layers_golden_fixture(name, kind):
+    """TransformerDecoderLayer / CrossAttentionTransformer from the backbone's factories against the live reference
+    (vit/transformer.py:165-384, vit/vit.py:373-433)."""
+    fix = load_golden(name)
+    kw = dict(fix["cfg"])
+    kw["dtype"] = DT[kw["dtype"]]
+    model = ViTConfig(**kw).instantiate(device=DEV)
+    layer = model.create_decoder_layer(device=DEV) if kind == "decoder" else model.create_cross_attention_layer(device=DEV)
+    part = fix[kind]
+    layer.load_state_dict({k: v.to(DEV) for k, v in part["state"].items()}, strict=True)
+    layer.eval()
+    mode = fix["mode"]
+    rtol = 1e-4 if mode == "fp32" else 2e-2
+    x, kv = fix["x"].to(DEV).requires_grad_(True), fix["kv"].to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "autocast_bf16"):
+        out = layer(x, kv)
+    out.float().square().mean().backward()
+    assert out.dtype == part["out"].dtype
+    close(out.detach(), part["out"], rtol, "out")
+    grtol = rtol if mode == "fp32" else 5e-2
+    close(x.grad, part["x_grad"], grtol, "x_grad", atol_scale=2.0)
+    close(kv.grad, part["kv_grad"], grtol, "kv_grad", atol_scale=2.0)
+    grads = {k: p.grad for k, p in layer.named_parameters() if p.grad is not None}
+    assert set(grads) == set(part["grads"])
+    for k, g in part["grads"].items():
+        close(grads[k], g, grtol, k, atol_scale=2.0)
+
+
+def test_decoder_layer_drop_path_matches_oracle_fp32():
+    """Drop-path in all three branches of the decoder layer: the subset selects samples of x and of kv alike
+    (vit/transformer.py:49-54, :262-284).  The oracle draws the same torch.randperm stream on the GPU."""
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=1, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="fourier",
+                    layer_scale=0.3, drop_path_rate=0.4, dtype=torch.float32)
+    model = cfg.instantiate(device=DEV)
+    layer = model.create_decoder_layer(device=DEV)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n_, p in layer.named_parameters():
+            if n_.endswith("out_proj.weight") or n_.endswith("fc2.weight"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    x0, kv0 = torch.randn(8, 5, 64, generator=g).to(DEV), torch.randn(8, 9, 64, generator=g).to(DEV)
+    layer.train()
+    x, kv = x0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+    torch.manual_seed(11)
+    out = layer(x, kv)
+    out.square().mean().backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, kvr = x0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+    torch.manual_seed(11)
+    with sdpa_kernel(SDPBackend.MATH):
+        ref = O.decoder_layer(oracle_cfg(cfg), params, "", xr, kvr, True, self_attn=True)
+    ref.square().mean().backward()
+    close(out.detach(), ref.detach(), 1e-4, "out")
+    close(x.grad, xr.grad, 1e-4, "x_grad", atol_scale=2.0)
+    close(kv.grad, kvr.grad, 1e-4, "kv_grad", atol_scale=2.0)
+    for k, p in layer.named_parameters():
+        close(p.grad, params[k].grad, 1e-4, k, atol_scale=2.0)
 
 
 def test_attentive_pool_head_trains_with_dropout():

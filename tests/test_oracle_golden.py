@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from conftest import golden_names, head_golden_names, load_golden
+from conftest import golden_names, head_golden_names, layer_golden_names, load_golden
 from oracle import vit_oracle as O
 
 DT = {"float32": torch.float32, "bfloat16": torch.bfloat16}
@@ -73,6 +73,29 @@ def test_oracle_heads_match_reference_fixture(name):
     got = {k: p.grad for k, p in params.items() if p.requires_grad and p.grad is not None}
     assert set(got) == set(fix["grads"])
     for k, g in fix["grads"].items():
+        torch.testing.assert_close(got[k], g, **t, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("name", layer_golden_names())
+@pytest.mark.parametrize("kind", ["decoder", "cross"])
+def test_oracle_decoder_layers_match_reference_fixture(name, kind):
+    fix = load_golden(name)
+    cfg = cfg_from(fix)
+    part = fix[kind]
+    torch.set_num_threads(1)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in part["state"].items()}
+    x, kv = fix["x"].clone().requires_grad_(True), fix["kv"].clone().requires_grad_(True)
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=fix["mode"] == "autocast_bf16"):
+        out = O.decoder_layer(cfg, params, "", x, kv, False, self_attn=kind == "decoder")
+    out.float().square().mean().backward()
+    t = tol(fix["mode"])
+    assert out.dtype == part["out"].dtype
+    torch.testing.assert_close(out.detach(), part["out"], **t)
+    torch.testing.assert_close(x.grad, part["x_grad"], **t)
+    torch.testing.assert_close(kv.grad, part["kv_grad"], **t)
+    got = {k: p.grad for k, p in params.items() if p.grad is not None}
+    assert set(got) == set(part["grads"])
+    for k, g in part["grads"].items():
         torch.testing.assert_close(got[k], g, **t, msg=lambda m, k=k: f"{k}: {m}")
 
 

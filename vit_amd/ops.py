@@ -325,11 +325,13 @@ class AttentionSublayerFn(torch.autograd.Function):
 
 
 class CrossAttentionFn(torch.autograd.Function):
-    """dropout(out_proj(SDPA(q_proj(norm(q)), kv_proj(kv))))   (vit/attention.py:112-162, :218-280): Lq queries attend to
-    Lk keys; the norm is on the query side only."""
+    """q -> q (+) alpha * gamma * dropout(out_proj(SDPA(q_proj(norm(q)), kv_proj(kv))))   (vit/attention.py:112-162,
+    :218-280; the residual form is the cross sub-layer of vit/transformer.py:262-284 and :367-384).  Lq queries attend
+    to Lk keys; the norm is on the query side only.  ``keep_idx`` (drop-path) selects samples of q and of kv alike."""
 
     @staticmethod
-    def forward(ctx, q, kv, norm_w, norm_b, w_q, b_q, w_kv, b_kv, w_out, b_out, qn_w, qn_b, kn_w, kn_b, opt):
+    def forward(ctx, q, kv, norm_w, norm_b, w_q, b_q, w_kv, b_kv, w_out, b_out, qn_w, qn_b, kn_w, kn_b, gamma, keep_idx,
+                opt):
         L.require_gpu(q, kv, norm_w, w_q, w_kv, w_out)
         B, Lq, D = q.shape
         Lk = kv.shape[1]
@@ -338,15 +340,20 @@ class CrossAttentionFn(torch.autograd.Function):
         Dh = opt["head_dim"]
         H = D // Dh
         tc = compute_dtype(w_q.dtype)
+        residual = opt["residual"]
+        tr = _residual_dtype(q, gamma, tc) if residual else tc
         training = opt["training"]
         p_attn = opt["attention_dropout"] if training else 0.0
         p_hid = opt["dropout"] if training else 0.0
-        Mq, Mk = B * Lq, B * Lk
+        rows = token_rows(keep_idx, Lq)
+        Bk = B if keep_idx is None else keep_idx.numel()
+        Mq, Mk = Bk * Lq, Bk * Lk
 
-        q2 = q.detach().reshape(Mq, D).contiguous()
+        q2 = _cast(q.reshape(B * Lq, D), tr if residual else q.dtype)
         qn, rstd, mean = K.norm_fwd(q2, norm_w.detach(), None if norm_b is None else norm_b.detach(), opt["eps"],
-                                    opt["layernorm"], tc)
-        kv2 = _cast(kv.reshape(Mk, D), tc)
+                                    opt["layernorm"], tc, rows)
+        kv_kept = kv.detach() if keep_idx is None else kv.detach().index_select(0, keep_idx)   # vit/transformer.py:49-54
+        kv2 = _cast(kv_kept.reshape(Mk, D), tc)
         wq, bq, wkv, bkv, wo, bo = (_cast(t, tc) for t in (w_q, b_q, w_kv, b_kv, w_out, b_out))
         qp = torch.empty((Mq, D), dtype=tc, device=q.device)
         K.gemm(qn, wq, trans_a=False, trans_b=False, M=Mq, N=D, K=D, out=qp, bias=bq)
@@ -364,27 +371,37 @@ class CrossAttentionFn(torch.autograd.Function):
             kvp[:, :D].copy_(nk.view(Mk, D))
             qk_saved = (pre_q, rq, mq, pre_k, rk, mk)
         seed_a = next_seed(q.device) if p_attn > 0 else 0
-        o, lse = K.attn_cross_fwd(qp, kvp, B, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
+        o, lse = K.attn_cross_fwd(qp, kvp, Bk, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
         seed_h = next_seed(q.device) if p_hid > 0 else 0
-        zero = torch.zeros((Mq, D), dtype=tc, device=q.device)
-        out, _ = _residual_gemm(o, wo, bo, zero, None, None, 1.0, p_hid, seed_h, want_aux=False)
-        ctx.save_for_backward(q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, qn_w, kn_w, *qk_saved)
-        ctx.meta = (B, Lq, Lk, D, H, Dh, tc, p_attn, p_hid, seed_a, seed_h, opt, q.dtype, kv.dtype, w_q.dtype,
+        g = _cast(gamma, tr)
+        if residual:
+            out, aux = _residual_gemm(o, wo, bo, q2, g, rows, opt["alpha"], p_hid, seed_h, want_aux=g is not None)
+            y = out.view(B, Lq, D)
+        else:
+            zero = torch.zeros((Mq, D), dtype=tc, device=q.device)
+            out, aux = _residual_gemm(o, wo, bo, zero, None, None, 1.0, p_hid, seed_h, want_aux=False)
+            y = out.view(Bk, Lq, D)
+        ctx.save_for_backward(q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, g, aux, rows, keep_idx, qn_w, kn_w,
+                              *qk_saved)
+        ctx.meta = (B, Bk, Lq, Lk, D, H, Dh, tc, tr, p_attn, p_hid, seed_a, seed_h, opt, q.dtype, kv.dtype, w_q.dtype,
                     norm_b is not None, b_q is not None, b_kv is not None, b_out is not None, qn_b is not None,
                     kn_b is not None)
-        return out.view(B, Lq, D)
+        return y
 
     @staticmethod
-    def backward(ctx, dout):
-        (q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, qn_w, kn_w, pre_q, rstd_q, mean_q, pre_k, rstd_k,
-         mean_k) = ctx.saved_tensors
-        (B, Lq, Lk, D, H, Dh, tc, p_attn, p_hid, seed_a, seed_h, opt, qdtype, kvdtype, wdtype, has_nb, has_bq, has_bkv,
-         has_bo, has_qnb, has_knb) = ctx.meta
+    def backward(ctx, dnew):
+        (q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, g, aux, rows, keep_idx, qn_w, kn_w, pre_q, rstd_q,
+         mean_q, pre_k, rstd_k, mean_k) = ctx.saved_tensors
+        (B, Bk, Lq, Lk, D, H, Dh, tc, tr, p_attn, p_hid, seed_a, seed_h, opt, qdtype, kvdtype, wdtype, has_nb, has_bq,
+         has_bkv, has_bo, has_qnb, has_knb) = ctx.meta
         need = ctx.needs_input_grad
-        Mq, Mk = B * Lq, B * Lk
-        dy, _ = _residual_grad(_cast(dout.reshape(Mq, D), tc), tc, None, None, Mq, 1.0, p_hid, seed_h, None, False)
+        residual = opt["residual"]
+        Mq, Mk = Bk * Lq, Bk * Lk
+        dnew2 = _cast(dnew.reshape(-1, D), tr)
+        dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, Mq,
+                                    opt["alpha"] if residual else 1.0, p_hid, seed_h, aux, need[14])
         do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[8], has_bo and need[9], wdtype)
-        dqp, dkvp = K.attn_cross_bwd(qp, kvp, o, lse, do, B, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
+        dqp, dkvp = K.attn_cross_bwd(qp, kvp, o, lse, do, Bk, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
         dqn = [None, None, None, None]
         if qn_w is not None:
             dpre = torch.empty_like(dqp)
@@ -398,13 +415,28 @@ class CrossAttentionFn(torch.autograd.Function):
             dkvp[:, :D].copy_(dk_pre.view(Mk, D))
         dqn_in, dwq, dbq = _linear_bwd(dqp, qn, wq, True, need[4], has_bq and need[5], wdtype)
         dkv_in, dwkv, dbkv = _linear_bwd(dkvp, kv2, wkv, need[1], need[6], has_bkv and need[7], wdtype)
-        dq_in = torch.empty_like(q2)
-        dnw, dnb = K.norm_bwd(dqn_in, q2, norm_w.detach(), rstd, mean, opt["layernorm"], None, dq_in, need[2],
-                              has_nb and need[3])
+        if residual:
+            if rows is None:
+                dq_in = torch.empty_like(dnew2)
+                add = dnew2
+            else:
+                dq_in = dnew2.clone()
+                add = dq_in
+        else:
+            dq_in = torch.zeros_like(q2) if rows is not None else torch.empty_like(q2)
+            add = None
+        dnw, dnb = K.norm_bwd(dqn_in, q2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dq_in, need[2],
+                              has_nb and need[3], rows)
         dq_in = dq_in.view(B, Lq, D)
+        if dq_in.dtype != qdtype:
+            dq_in = dq_in.to(qdtype)
         if dkv_in is not None:
-            dkv_in = dkv_in.view(B, Lk, D).to(kvdtype)
-        return (dq_in if need[0] else None, dkv_in, dnw, dnb, dwq, dbq, dwkv, dbkv, dwo, dbo, *dqn, None)
+            dkv_in = dkv_in.view(Bk, Lk, D).to(kvdtype)
+            if keep_idx is not None:   # samples outside the drop-path subset did not take part
+                dkv_in = dkv_in.new_zeros((B, Lk, D)).index_copy_(0, keep_idx, dkv_in)
+        if dgamma is not None and dgamma.dtype != g.dtype:
+            dgamma = dgamma.to(g.dtype)
+        return (dq_in if need[0] else None, dkv_in, dnw, dnb, dwq, dbq, dwkv, dbkv, dwo, dbo, *dqn, dgamma, None, None)
 
 
 class MlpSublayerFn(torch.autograd.Function):

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from .attention import SelfAttention
+from .attention import CrossAttention, SelfAttention
 from .fused import NormMLP
 from .initialization import zero_bias_if_present
 from .layer_scale import LayerScale
@@ -88,3 +88,86 @@ class TransformerEncoderLayer(nn.Module):
         x = self.self_attention.fused_residual(x, rope, g_attn, idx, scale)
         idx, scale = _select_keep_indices(x, self.drop_path_rate, self.training)
         return self.mlp.fused_residual(x, g_mlp, idx, scale)
+
+
+def _scale_or_identity(hidden_size: int, layer_scale: Optional[float], kw: dict) -> nn.Module:
+    return LayerScale(hidden_size, layer_scale, inplace=True, **kw) if layer_scale is not None else nn.Identity()
+
+
+class TransformerDecoderLayer(nn.Module):
+    """Self-attention, cross-attention to ``kv``, MLP; each a pre-norm residual branch with its own drop-path subset
+    and layer scale (vit/transformer.py:165-284)."""
+
+    def __init__(self, hidden_size: int, ffn_hidden_size: int, num_attention_heads: int, hidden_dropout: float = 0.1,
+                 attention_dropout: float = 0.1, attention_bias: bool = True, mlp_bias: bool = True,
+                 activation: str = "gelu", drop_path_rate: float = 0.0, eps: float = 1e-5,
+                 layer_scale: Optional[float] = None, glu_limit: Optional[float] = None,
+                 glu_extra_bias: Optional[float] = None, mlp_quantization_config: Any = None,
+                 qkv_quantization_config: Any = None, attn_quantization_config: Any = None, device=None, dtype=None,
+                 norm_type: str = "rmsnorm", qk_normalization: bool = False):
+        super().__init__()
+        kw = {"device": device, "dtype": dtype}
+        self.drop_path_rate = drop_path_rate
+        self.self_attention = SelfAttention(hidden_size, num_attention_heads, hidden_dropout, attention_dropout,
+                                            bias=attention_bias, eps=eps, norm_type=norm_type,
+                                            qk_normalization=qk_normalization, **kw)
+        self.cross_attention = CrossAttention(hidden_size, num_attention_heads, hidden_dropout, attention_dropout,
+                                              bias=attention_bias, eps=eps, norm_type=norm_type,
+                                              qk_normalization=qk_normalization, **kw)
+        self.mlp = NormMLP(hidden_size, ffn_hidden_size, bias=mlp_bias, activation=activation, eps=eps,
+                           dropout=hidden_dropout, limit=glu_limit, extra_bias=glu_extra_bias, norm_type=norm_type, **kw)
+        self.layer_scale_attn = _scale_or_identity(hidden_size, layer_scale, kw)
+        self.layer_scale_mlp = _scale_or_identity(hidden_size, layer_scale, kw)
+        self.layer_scale_cross = _scale_or_identity(hidden_size, layer_scale, kw)
+        _zero_residual_outputs(self.self_attention.out_proj, self.cross_attention.out_proj, self.mlp.fc2)
+        self.apply_quantization(mlp_quantization_config, qkv_quantization_config, attn_quantization_config)
+
+    def apply_quantization(self, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
+                           attn_quantization_config: Any = None) -> None:
+        if any(c is not None for c in (mlp_quantization_config, qkv_quantization_config, attn_quantization_config)):
+            raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
+
+    def forward(self, x: Tensor, kv: Tensor, rope_q: Optional[Tensor] = None, rope_k: Optional[Tensor] = None) -> Tensor:
+        idx, scale = _select_keep_indices(x, self.drop_path_rate, self.training)
+        x = self.self_attention.fused_residual(x, rope_q, getattr(self.layer_scale_attn, "gamma", None), idx, scale)
+        idx, scale = _select_keep_indices(x, self.drop_path_rate, self.training)
+        x = self.cross_attention.fused_residual(x, kv, getattr(self.layer_scale_cross, "gamma", None), idx, scale,
+                                                rope_q, rope_k)
+        idx, scale = _select_keep_indices(x, self.drop_path_rate, self.training)
+        return self.mlp.fused_residual(x, getattr(self.layer_scale_mlp, "gamma", None), idx, scale)
+
+
+class CrossAttentionTransformer(nn.Module):
+    """Cross-attention to ``kv``, then MLP (vit/transformer.py:290-384)."""
+
+    def __init__(self, hidden_size: int, ffn_hidden_size: int, num_attention_heads: int, hidden_dropout: float = 0.1,
+                 attention_dropout: float = 0.1, attention_bias: bool = True, mlp_bias: bool = True,
+                 activation: str = "gelu", drop_path_rate: float = 0.0, eps: float = 1e-5,
+                 layer_scale: Optional[float] = None, glu_limit: Optional[float] = None,
+                 glu_extra_bias: Optional[float] = None, mlp_quantization_config: Any = None,
+                 qkv_quantization_config: Any = None, attn_quantization_config: Any = None, device=None, dtype=None,
+                 norm_type: str = "rmsnorm", qk_normalization: bool = False):
+        super().__init__()
+        kw = {"device": device, "dtype": dtype}
+        self.drop_path_rate = drop_path_rate
+        self.cross_attention = CrossAttention(hidden_size, num_attention_heads, hidden_dropout, attention_dropout,
+                                              bias=attention_bias, eps=eps, norm_type=norm_type,
+                                              qk_normalization=qk_normalization, **kw)
+        self.mlp = NormMLP(hidden_size, ffn_hidden_size, bias=mlp_bias, activation=activation, eps=eps,
+                           dropout=hidden_dropout, limit=glu_limit, extra_bias=glu_extra_bias, norm_type=norm_type, **kw)
+        self.layer_scale_cross = _scale_or_identity(hidden_size, layer_scale, kw)
+        self.layer_scale_mlp = _scale_or_identity(hidden_size, layer_scale, kw)
+        _zero_residual_outputs(self.cross_attention.out_proj, self.mlp.fc2)
+        self.apply_quantization(mlp_quantization_config, qkv_quantization_config, attn_quantization_config)
+
+    def apply_quantization(self, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
+                           attn_quantization_config: Any = None) -> None:
+        if any(c is not None for c in (mlp_quantization_config, qkv_quantization_config, attn_quantization_config)):
+            raise NotImplementedError("vit_amd: torchao quantization is outside the encoder hot path")
+
+    def forward(self, x: Tensor, kv: Tensor, rope_q: Optional[Tensor] = None, rope_k: Optional[Tensor] = None) -> Tensor:
+        idx, scale = _select_keep_indices(x, self.drop_path_rate, self.training)
+        x = self.cross_attention.fused_residual(x, kv, getattr(self.layer_scale_cross, "gamma", None), idx, scale,
+                                                rope_q, rope_k)
+        idx, scale = _select_keep_indices(x, self.drop_path_rate, self.training)
+        return self.mlp.fused_residual(x, getattr(self.layer_scale_mlp, "gamma", None), idx, scale)

@@ -3,7 +3,8 @@ forward signature; every arithmetic step of forward/backward runs in libvitk ker
 
 Token masks (masked pre-training) drop tokens ahead of the blocks and give every sample its own RoPE rows.
 Heads: the linear head and the attentive-pool head (vit_amd/head.py).
-Not provided (outside the encoder hot path): dense-prediction heads, decoder layer factories,
+Decoder / cross-attention layers of the backbone's width: create_decoder_layer, create_cross_attention_layer.
+Not provided (outside the encoder hot path): dense-prediction heads,
 attention-weight visualisation, torchao quantization.  They raise NotImplementedError rather than fall back."""
 from __future__ import annotations
 
@@ -23,7 +24,7 @@ from .norm import make_norm
 from .patch_embed import PatchEmbed2d
 from .rope import RopePositionEmbedding
 from .tokens import apply_mask, create_mask
-from .transformer import TransformerEncoderLayer
+from .transformer import CrossAttentionTransformer, TransformerDecoderLayer, TransformerEncoderLayer
 
 __all__ = ["ViT", "ViTConfig", "ViTFeatures"]
 
@@ -69,10 +70,9 @@ class ViT(nn.Module):
     def config(self) -> ViTConfig:
         return self._config
 
-    def create_encoder_layer(self, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
-                             attn_quantization_config: Any = None, device=None, dtype=None) -> TransformerEncoderLayer:
+    def _layer(self, layer_type, mlp_quantization_config, qkv_quantization_config, attn_quantization_config, device, dtype):
         c = self._config
-        return TransformerEncoderLayer(
+        return layer_type(
             c.hidden_size, c.ffn_hidden_size, c.num_attention_heads, hidden_dropout=c.hidden_dropout,
             attention_dropout=c.attention_dropout, attention_bias=c.attention_bias, mlp_bias=c.mlp_bias,
             activation=c.activation, norm_type=c.norm_type, qk_normalization=c.qk_normalization,
@@ -80,6 +80,24 @@ class ViT(nn.Module):
             glu_extra_bias=c.glu_extra_bias, mlp_quantization_config=mlp_quantization_config,
             qkv_quantization_config=qkv_quantization_config, attn_quantization_config=attn_quantization_config,
             device=device, dtype=c.dtype if dtype is None else dtype)
+
+    def create_encoder_layer(self, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
+                             attn_quantization_config: Any = None, device=None, dtype=None) -> TransformerEncoderLayer:
+        return self._layer(TransformerEncoderLayer, mlp_quantization_config, qkv_quantization_config,
+                           attn_quantization_config, device, dtype)
+
+    def create_decoder_layer(self, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
+                             attn_quantization_config: Any = None, device=None, dtype=None) -> TransformerDecoderLayer:
+        """A layer of the backbone's width with self-attention, cross-attention and MLP (vit/vit.py:373-402)."""
+        return self._layer(TransformerDecoderLayer, mlp_quantization_config, qkv_quantization_config,
+                           attn_quantization_config, device, dtype)
+
+    def create_cross_attention_layer(self, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
+                                     attn_quantization_config: Any = None, device=None,
+                                     dtype=None) -> CrossAttentionTransformer:
+        """Cross-attention + MLP (vit/vit.py:404-433)."""
+        return self._layer(CrossAttentionTransformer, mlp_quantization_config, qkv_quantization_config,
+                           attn_quantization_config, device, dtype)
 
     def create_head(self, name: str, head_config: Any, device: Optional[torch.device] = None, dtype=None) -> nn.Module:
         """vit/vit.py:435-447."""

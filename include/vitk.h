@@ -148,6 +148,12 @@ int vitk_attn_bwd(const VitkAttn* a, void* stream);
  * sample keeps its own subset of positions (vit/vit.py:522-527, vit/rope.py:139-163 with a 5-D table). */
 int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
                  int64_t prefix, int inverse, int emulate_bf16, int per_sample, void* stream);
+/* The same rotation on the first nsec sections (H*Dh wide each) of rows that are row_stride elements apart:
+ * q alone (row_stride = H*Dh, nsec = 1) or the k half of a packed [k | v] projection (row_stride = 2*H*Dh,
+ * nsec = 1) -- rope_q / rope_k of project_q_kv_packed, vit/attention.py:156-159. */
+int vitk_rope_rows(void* x, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
+                   int64_t prefix, int64_t row_stride, int64_t nsec, int inverse, int emulate_bf16,
+                   int per_sample, void* stream);
 
 /* ---- MLP activation: vit/fused.py:115-116 (plain) and :154-161 (GLU), vit/helpers.py:9-48 ----------
  * plain: h = dropout(act(p));  GLU: lin = p[:, :F], glu = p[:, F:], h = dropout(act(min(glu,limit)) *

@@ -330,8 +330,9 @@ def vit_forward(cfg: OracleConfig, sd: dict, x: Tensor, *, training: bool = Fals
 # heads (vit/head.py, vit/attention.py:112-162, :218-280, :594-667)
 # --------------------------------------------------------------------------------------------
 def cross_attention(cfg: OracleConfig, sd: dict, pre: str, q: Tensor, kv: Tensor, num_heads: int, training: bool = False,
-                    attention_dropout: float = 0.0, hidden_dropout: float = 0.0) -> Tensor:
-    """attention_q_kv_packed, vit/attention.py:218-280: norm on the query side only, no RoPE."""
+                    attention_dropout: float = 0.0, hidden_dropout: float = 0.0, rope_q: Tensor | None = None,
+                    rope_k: Tensor | None = None) -> Tensor:
+    """attention_q_kv_packed, vit/attention.py:218-280: norm on the query side only."""
     ln = cfg.norm_type == "layernorm"
     D = q.shape[-1]
     dh = D // num_heads
@@ -346,6 +347,10 @@ def cross_attention(cfg: OracleConfig, sd: dict, pre: str, q: Tensor, kv: Tensor
     if cfg.qk_normalization:
         qp = apply_norm(qp, sd[pre + "q_norm.weight"], sd.get(pre + "q_norm.bias"), 1e-5, ln)
         k = apply_norm(k, sd[pre + "k_norm.weight"], sd.get(pre + "k_norm.bias"), 1e-5, ln)
+    if rope_q is not None:
+        qp = apply_rope(qp, rope_q)
+    if rope_k is not None:
+        k = apply_rope(k, rope_k)
     o = F.scaled_dot_product_attention(qp, k, v, attn_mask=None, dropout_p=attention_dropout if training else 0.0,
                                        is_causal=False, enable_gqa=True)
     o = o.transpose(1, 2).reshape(B, Lq, D)
@@ -353,7 +358,8 @@ def cross_attention(cfg: OracleConfig, sd: dict, pre: str, q: Tensor, kv: Tensor
     return F.dropout(o, p=hidden_dropout, training=training)
 
 
-def decoder_layer(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, kv: Tensor, training: bool, self_attn: bool) -> Tensor:
+def decoder_layer(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, kv: Tensor, training: bool, self_attn: bool,
+                  rope_q: Tensor | None = None, rope_k: Tensor | None = None) -> Tensor:
     """TransformerDecoderLayer.forward (vit/transformer.py:262-284) when ``self_attn``, else
     CrossAttentionTransformer.forward (:367-384).  ``pre`` is the prefix of the layer's keys in ``sd``."""
     def scaled(o, name):
@@ -362,12 +368,13 @@ def decoder_layer(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, kv: Tensor, 
     B = x.shape[0]
     if self_attn:
         xr, idx, scale = select_residual_subset(x, cfg.drop_path_rate, training)
-        o = self_attention(cfg, sd, pre + "self_attention.", xr, None, training)
+        o = self_attention(cfg, sd, pre + "self_attention.", xr, subset_batched_rope(rope_q, idx, B), training)
         x = merge_residual_subset(x, scaled(o, "layer_scale_attn"), idx, scale)
     xr, idx, scale = select_residual_subset(x, cfg.drop_path_rate, training)
     kvr = kv if idx is None or kv.shape[0] != B else kv.index_select(0, idx)
     o = cross_attention(cfg, sd, pre + "cross_attention.", xr, kvr, cfg.num_attention_heads, training,
-                        cfg.attention_dropout, cfg.hidden_dropout)
+                        cfg.attention_dropout, cfg.hidden_dropout, subset_batched_rope(rope_q, idx, B),
+                        subset_batched_rope(rope_k, idx, B))
     x = merge_residual_subset(x, scaled(o, "layer_scale_cross"), idx, scale)
     xr, idx, scale = select_residual_subset(x, cfg.drop_path_rate, training)
     o = norm_mlp(cfg, sd, pre + "mlp.", xr, training)

@@ -187,6 +187,53 @@ def test_decoder_layer_drop_path_matches_oracle_fp32():
         close(p.grad, params[k].grad, 1e-4, k, atol_scale=2.0)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "autocast"])
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_decoder_layer_with_rope_matches_oracle(mode, per_sample):
+    """rope_q on the queries (self- and cross-attention), rope_k on the keys of the memory (vit/attention.py:156-159);
+    per-sample tables [2, B, 1, N, Dh] follow the drop-path subset (vit/transformer.py:41-46)."""
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+
+    if per_sample and mode == "autocast":
+        pytest.skip("the reference's drop-path merge (index_add of a bf16 branch into the fp32 stream) raises under autocast")
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=1, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="rope",
+                    drop_path_rate=0.4 if per_sample else 0.0, dtype=torch.float32)
+    model = cfg.instantiate(device=DEV)
+    layer = model.create_decoder_layer(device=DEV)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n_, p in layer.named_parameters():
+            if n_.endswith("out_proj.weight") or n_.endswith("fc2.weight"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    B = 6
+    rq, rk = model.rope(H=2, W=3), model.rope(H=3, W=4)   # 6 rotated query rows (+1 prefix row), 12 key rows
+    if per_sample:
+        rq = torch.stack([rq[:, torch.randperm(6, generator=g)] for _ in range(B)], 1)[:, :, None].to(DEV)
+        rk = torch.stack([rk[:, torch.randperm(12, generator=g)] for _ in range(B)], 1)[:, :, None].to(DEV)
+    x0, kv0 = torch.randn(B, 7, 64, generator=g).to(DEV), torch.randn(B, 12, 64, generator=g).to(DEV)
+    ac = mode == "autocast"
+    layer.train()
+    x, kv = x0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+    torch.manual_seed(11)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+        out = layer(x, kv, rope_q=rq, rope_k=rk)
+    out.float().square().mean().backward()
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xr, kvr = x0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+    torch.manual_seed(11)
+    with sdpa_kernel(SDPBackend.MATH), torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+        ref = O.decoder_layer(oracle_cfg(cfg), params, "", xr, kvr, True, True, rq, rk)
+    ref.float().square().mean().backward()
+    rtol, grtol = (1e-4, 1e-4) if mode == "fp32" else (2e-2, 5e-2)
+    assert out.dtype == ref.dtype
+    close(out.detach(), ref.detach(), rtol, "out")
+    close(x.grad, xr.grad, grtol, "x_grad", atol_scale=2.0)
+    close(kv.grad, kvr.grad, grtol, "kv_grad", atol_scale=2.0)
+    for k, p in layer.named_parameters():
+        close(p.grad, params[k].grad, grtol, k, atol_scale=2.0)
+
+
 def test_attentive_pool_head_trains_with_dropout():
     """Dropout in the pool and the head: eval differs from train, the mask replays in backward (finite gradients, and
     a second backward through a fresh forward with the same seed gives the same gradients)."""

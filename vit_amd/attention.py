@@ -105,8 +105,6 @@ def attention_q_kv_packed(q, kv, w_q, b_q, w_kv, b_kv, w_norm, b_norm, use_layer
     """Same positional signature as the reference function (vit/attention.py:218-280)."""
     if attn_mask is not None:
         raise NotImplementedError("vit_amd: attention masks are not built")
-    if rope_q is not None or rope_k is not None:
-        raise NotImplementedError("vit_amd: RoPE on cross-attention operands is not built")
     if qk_normalization:
         assert q_norm_weight is not None and k_norm_weight is not None
     else:
@@ -114,7 +112,7 @@ def attention_q_kv_packed(q, kv, w_q, b_q, w_kv, b_kv, w_norm, b_norm, use_layer
     opt = _sublayer_opts(head_dim=head_dim, eps=eps, layernorm=use_layer_norm, attention_dropout=attention_dropout,
                          dropout=dropout, training=training, residual=False, qk_eps=qk_eps, qk_layernorm=qk_use_layer_norm)
     return ops.CrossAttentionFn.apply(q, kv, w_norm, b_norm, w_q, b_q, w_kv, b_kv, w_out, b_out, q_norm_weight, q_norm_bias,
-                                      k_norm_weight, k_norm_bias, None, None, opt)
+                                      k_norm_weight, k_norm_bias, None, None, rope_q, rope_k, opt)
 
 
 class CrossAttention(nn.Module):
@@ -163,15 +161,13 @@ class CrossAttention(nn.Module):
                        rope_q: Optional[Tensor] = None, rope_k: Optional[Tensor] = None) -> Tensor:
         """x (+) alpha * gamma * cross_attention(x[keep_idx], kv[keep_idx]): residual, layer scale and the drop-path merge
         in the out_proj epilogue (the cross sub-layer of vit/transformer.py:262-284)."""
-        if rope_q is not None or rope_k is not None:
-            raise NotImplementedError("vit_amd: RoPE on cross-attention operands is not built")
         qw, qb, kw_, kb, qk_eps = self._qk_norm_inputs()
         opt = _sublayer_opts(head_dim=self._head_dim, eps=self.norm.eps or 1e-5, layernorm=self._use_layer_norm,
                              attention_dropout=self.attention_dropout.p, dropout=self.dropout.p, training=self.training,
                              residual=True, alpha=alpha, qk_eps=qk_eps, qk_layernorm=self._use_layer_norm)
         return ops.CrossAttentionFn.apply(x, kv, self.norm.weight, get_norm_bias(self.norm), self.q_proj.weight,
                                           self.q_proj.bias, self.kv_proj.weight, self.kv_proj.bias, self.out_proj.weight,
-                                          self.out_proj.bias, qw, qb, kw_, kb, gamma, keep_idx, opt)
+                                          self.out_proj.bias, qw, qb, kw_, kb, gamma, keep_idx, rope_q, rope_k, opt)
 
     def forward(self, q: Tensor, kv: Tensor, attn_mask: Optional[Tensor] = None, rope_q: Optional[Tensor] = None,
                 rope_k: Optional[Tensor] = None) -> Tensor:

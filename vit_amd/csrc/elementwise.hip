@@ -560,13 +560,13 @@ extern "C" int vitk_act_bwd(const void* dh, const void* p, void* dp, int dtype, 
 //   inverse:  g1 = y1*cos1 + y2*sin2 ; g2 = y2*cos2 - y1*sin1     (transpose of the forward map)
 // ------------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const float* __restrict__ table, int64_t B,
-                                                 int64_t S, int64_t H, int64_t Dh, int64_t prefix, int inverse, int emu,
-                                                 int per_sample) {
+__global__ __launch_bounds__(256) void rope_rows_k(T* __restrict__ x, const float* __restrict__ table, int64_t B,
+                                                   int64_t S, int64_t H, int64_t Dh, int64_t prefix, int64_t row_stride,
+                                                   int64_t nsec, int inverse, int emu, int per_sample) {
   const int64_t half = Dh / 2;
   const int64_t np = half / 2;          // pairs per head
   const int64_t N = S - prefix;         // rotated rows per sample
-  const int64_t total = B * N * 2 * H * np;
+  const int64_t total = B * N * nsec * H * np;
   const int64_t tbs = per_sample ? N * Dh : 0;   // table stride between samples
   const float* sinT = table;
   const float* cosT = table + (per_sample ? B : 1) * N * Dh;
@@ -574,11 +574,11 @@ __global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const floa
     int64_t t = i;
     const int64_t pr = t % np; t /= np;
     const int64_t h = t % H; t /= H;
-    const int64_t which = t % 2; t /= 2;
+    const int64_t which = t % nsec; t /= nsec;
     const int64_t n = t % N;
     const int64_t b = t / N;
     const int64_t d = pr * 2;
-    T* px = qkv + ((b * S + prefix + n) * 3 + which) * (H * Dh) + h * Dh;
+    T* px = x + (b * S + prefix + n) * row_stride + which * (H * Dh) + h * Dh;
     const float* ps = sinT + b * tbs + n * Dh;
     const float* pc = cosT + b * tbs + n * Dh;
 #pragma unroll
@@ -599,21 +599,29 @@ __global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const floa
   }
 }
 
-extern "C" int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
-                            int64_t prefix, int inverse, int emulate_bf16, int per_sample, void* stream) {
-  VITK_REQUIRE(qkv && table, "rope: null pointer");
+extern "C" int vitk_rope_rows(void* x, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
+                              int64_t prefix, int64_t row_stride, int64_t nsec, int inverse, int emulate_bf16,
+                              int per_sample, void* stream) {
+  VITK_REQUIRE(x && table, "rope: null pointer");
   VITK_REQUIRE(Dh > 0 && Dh % 4 == 0, "rope: head_dim=%lld must be a multiple of 4", (long long)Dh);
   VITK_REQUIRE(prefix >= 0 && prefix <= S, "rope: prefix=%lld outside [0, %lld]", (long long)prefix, (long long)S);
-  const int64_t total = B * (S - prefix) * 2 * H * (Dh / 4);
+  VITK_REQUIRE(nsec >= 1 && row_stride >= nsec * H * Dh, "rope: row_stride=%lld cannot hold %lld sections of %lld",
+               (long long)row_stride, (long long)nsec, (long long)(H * Dh));
+  const int64_t total = B * (S - prefix) * nsec * H * (Dh / 4);
   if (total == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ew_grid(total)), block(256);
   DISPATCH_DTYPE(dtype, T, {
-    hipLaunchKernelGGL((rope_qk_k<T>), grid, block, 0, st, (T*)qkv, table, B, S, H, Dh, prefix, inverse, emulate_bf16,
-                       per_sample);
+    hipLaunchKernelGGL((rope_rows_k<T>), grid, block, 0, st, (T*)x, table, B, S, H, Dh, prefix, row_stride, nsec, inverse,
+                       emulate_bf16, per_sample);
   });
   VITK_LAUNCH_CHECK("rope");
   return 0;
+}
+
+extern "C" int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
+                            int64_t prefix, int inverse, int emulate_bf16, int per_sample, void* stream) {
+  return vitk_rope_rows(qkv, dtype, table, B, S, H, Dh, prefix, 3 * H * Dh, 2, inverse, emulate_bf16, per_sample, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

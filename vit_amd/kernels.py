@@ -257,6 +257,21 @@ def rope_qk_(qkv: Tensor, table_f32: Tensor, B: int, S: int, H: int, Dh: int, pr
     return qkv
 
 
+def rope_rows_(x: Tensor, table_f32: Tensor, B: int, S: int, H: int, Dh: int, inverse: bool, emulate_bf16: bool) -> Tensor:
+    """Rotate, in place, the first H*Dh columns of x [B*S, W] (W = H*Dh for q, 2*H*Dh for a packed [k | v])."""
+    lib = L.load()
+    L.require_gpu(x, table_f32)
+    assert x.is_contiguous() and x.shape[0] == B * S and x.shape[1] >= H * Dh
+    assert table_f32.is_contiguous() and table_f32.dtype == torch.float32
+    per_sample = table_f32.dim() == 4
+    n_rot = table_f32.shape[-2]
+    want = (2, B, n_rot, Dh) if per_sample else (2, n_rot, Dh)
+    assert tuple(table_f32.shape) == want and n_rot <= S, f"rope table {tuple(table_f32.shape)} vs {want}"
+    L.check(lib.vitk_rope_rows(L.ptr(x), L.dt(x), L.ptr(table_f32), B, S, H, Dh, S - n_rot, x.shape[1], 1, int(inverse),
+                               int(emulate_bf16), int(per_sample), L.stream()))
+    return x
+
+
 def act_fwd(p: Tensor, F: int, glu: bool, act: int, limit: Optional[float], extra: Optional[float], drop_p: float,
             seed: int) -> Tensor:
     lib = L.load()

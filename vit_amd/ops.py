@@ -209,6 +209,26 @@ def _residual_grad(dnew2: Tensor, tc: torch.dtype, gamma: Optional[Tensor], rows
     return dy, dgamma
 
 
+def _rope_table(rope: Optional[Tensor], keep_idx: Optional[Tensor], B: int, Bk: int, tc: torch.dtype):
+    """(fp32 table for the rope kernels, emulate-bf16 flag).  [2, N, Dh] is shared by all samples; [2, B, 1, N', Dh] holds
+    one table per sample (masked tokens, vit/vit.py:522-527) and follows a drop-path subset (vit/transformer.py:41-46)."""
+    if rope is None:
+        return None, False
+    emu = rope.dtype == torch.bfloat16 and tc == torch.bfloat16
+    if rope.dim() == 5:
+        table = rope.detach()[:, :, 0].to(torch.float32)
+        if keep_idx is not None and table.shape[1] == B:
+            table = table.index_select(1, keep_idx)
+        table = table.contiguous()
+        if table.shape[1] != Bk:
+            raise ValueError(f"vit_amd: RoPE table for {table.shape[1]} samples, batch is {Bk}")
+    elif rope.dim() == 3:
+        table = rope.detach().to(torch.float32).contiguous()
+    else:
+        raise ValueError(f"vit_amd: RoPE table must be [2, N, Dh] or [2, B, 1, N, Dh], got {tuple(rope.shape)}")
+    return table, emu
+
+
 class AttentionSublayerFn(torch.autograd.Function):
     """x -> x (+) alpha * gamma * dropout(out_proj(SDPA(rope(qkv_proj(norm(x))))))   (vit/attention.py:163-215)."""
 
@@ -246,21 +266,8 @@ class AttentionSublayerFn(torch.autograd.Function):
                                          opt["qk_layernorm"], tc)
                 qkv[:, which * D:(which + 1) * D].copy_(nrm.view(M, D))
                 qk_saved += [pre, r_, m_]
-        table, emu, per_sample = None, False, False
-        if rope is not None:
-            emu = rope.dtype == torch.bfloat16 and tc == torch.bfloat16
-            if rope.dim() == 5:   # [2, B, 1, N', Dh]: one table per sample (masked tokens, vit/vit.py:522-527)
-                per_sample = True
-                table = rope.detach()[:, :, 0].to(torch.float32)
-                if keep_idx is not None:   # vit/transformer.py:41-46
-                    table = table.index_select(1, keep_idx)
-                table = table.contiguous()
-                if table.shape[1] != Bk:
-                    raise ValueError(f"vit_amd: RoPE table for {table.shape[1]} samples, batch is {Bk}")
-            elif rope.dim() == 3:
-                table = rope.detach().to(torch.float32).contiguous()
-            else:
-                raise ValueError(f"vit_amd: RoPE table must be [2, N, Dh] or [2, B, 1, N, Dh], got {tuple(rope.shape)}")
+        table, emu = _rope_table(rope, keep_idx, B, Bk, tc)
+        if table is not None:
             K.rope_qk_(qkv, table, Bk, S, H, Dh, S - table.shape[-2], False, emu)
         seed_a = next_seed(x.device) if p_attn > 0 else 0
         o, lse = K.attn_fwd(qkv, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
@@ -331,7 +338,7 @@ class CrossAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, kv, norm_w, norm_b, w_q, b_q, w_kv, b_kv, w_out, b_out, qn_w, qn_b, kn_w, kn_b, gamma, keep_idx,
-                opt):
+                rope_q, rope_k, opt):
         L.require_gpu(q, kv, norm_w, w_q, w_kv, w_out)
         B, Lq, D = q.shape
         Lk = kv.shape[1]
@@ -370,6 +377,14 @@ class CrossAttentionFn(torch.autograd.Function):
                                     opt["qk_layernorm"], tc)
             kvp[:, :D].copy_(nk.view(Mk, D))
             qk_saved = (pre_q, rq, mq, pre_k, rk, mk)
+        tq, emu_q = _rope_table(rope_q, keep_idx, B, Bk, tc)   # vit/attention.py:156-159
+        tk, emu_k = _rope_table(rope_k, keep_idx, B, Bk, tc)
+        if tq is not None:
+            if not qp.is_contiguous():
+                qp = qp.contiguous()
+            K.rope_rows_(qp, tq, Bk, Lq, H, Dh, False, emu_q)
+        if tk is not None:
+            K.rope_rows_(kvp, tk, Bk, Lk, H, Dh, False, emu_k)
         seed_a = next_seed(q.device) if p_attn > 0 else 0
         o, lse = K.attn_cross_fwd(qp, kvp, Bk, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
         seed_h = next_seed(q.device) if p_hid > 0 else 0
@@ -382,7 +397,8 @@ class CrossAttentionFn(torch.autograd.Function):
             out, aux = _residual_gemm(o, wo, bo, zero, None, None, 1.0, p_hid, seed_h, want_aux=False)
             y = out.view(Bk, Lq, D)
         ctx.save_for_backward(q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, g, aux, rows, keep_idx, qn_w, kn_w,
-                              *qk_saved)
+                              tq, tk, *qk_saved)
+        ctx.emu = (emu_q, emu_k)
         ctx.meta = (B, Bk, Lq, Lk, D, H, Dh, tc, tr, p_attn, p_hid, seed_a, seed_h, opt, q.dtype, kv.dtype, w_q.dtype,
                     norm_b is not None, b_q is not None, b_kv is not None, b_out is not None, qn_b is not None,
                     kn_b is not None)
@@ -390,8 +406,8 @@ class CrossAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dnew):
-        (q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, g, aux, rows, keep_idx, qn_w, kn_w, pre_q, rstd_q,
-         mean_q, pre_k, rstd_k, mean_k) = ctx.saved_tensors
+        (q2, norm_w, rstd, mean, qn, kv2, qp, kvp, o, lse, wq, wkv, wo, g, aux, rows, keep_idx, qn_w, kn_w, tq, tk, pre_q,
+         rstd_q, mean_q, pre_k, rstd_k, mean_k) = ctx.saved_tensors
         (B, Bk, Lq, Lk, D, H, Dh, tc, tr, p_attn, p_hid, seed_a, seed_h, opt, qdtype, kvdtype, wdtype, has_nb, has_bq,
          has_bkv, has_bo, has_qnb, has_knb) = ctx.meta
         need = ctx.needs_input_grad
@@ -402,6 +418,10 @@ class CrossAttentionFn(torch.autograd.Function):
                                     opt["alpha"] if residual else 1.0, p_hid, seed_h, aux, need[14])
         do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[8], has_bo and need[9], wdtype)
         dqp, dkvp = K.attn_cross_bwd(qp, kvp, o, lse, do, Bk, Lq, Lk, H, Dh, Dh ** -0.5, p_attn, seed_a)
+        if tq is not None:
+            K.rope_rows_(dqp, tq, Bk, Lq, H, Dh, True, ctx.emu[0])
+        if tk is not None:
+            K.rope_rows_(dkvp, tk, Bk, Lk, H, Dh, True, ctx.emu[1])
         dqn = [None, None, None, None]
         if qn_w is not None:
             dpre = torch.empty_like(dqp)
@@ -436,7 +456,8 @@ class CrossAttentionFn(torch.autograd.Function):
                 dkv_in = dkv_in.new_zeros((B, Lk, D)).index_copy_(0, keep_idx, dkv_in)
         if dgamma is not None and dgamma.dtype != g.dtype:
             dgamma = dgamma.to(g.dtype)
-        return (dq_in if need[0] else None, dkv_in, dnw, dnb, dwq, dbq, dwkv, dbkv, dwo, dbo, *dqn, dgamma, None, None)
+        return (dq_in if need[0] else None, dkv_in, dnw, dnb, dwq, dbq, dwkv, dbkv, dwo, dbo, *dqn, dgamma, None, None, None,
+                None)
 
 
 class MlpSublayerFn(torch.autograd.Function):

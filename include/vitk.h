@@ -139,6 +139,9 @@ typedef struct VitkAttn {
 
 int vitk_attn_fwd(const VitkAttn* a, void* stream);
 int vitk_attn_bwd(const VitkAttn* a, void* stream);
+/* softmax(scale * q k^T) itself, [B, H, S, Sk or S] fp32: attention_weights_qkv_packed / _q_kv_packed,
+ * vit/attention.py:281-373 (diagnostics; v, o, lse of the descriptor are not used). */
+int vitk_attn_weights(const VitkAttn* a, float* weights, void* stream);
 
 /* ---- RoPE: vit/rope.py:139-163 (apply_rope: half-split rotation, prefix rows untouched) -------------
  * In place on the q and k sections of the packed projection qkv[B*S, 3*H*Dh]. table = [2, S-prefix, Dh]

@@ -194,11 +194,14 @@ def make_heads(ref, name, overrides, mode, seed):
         outs = {"pool": model.heads["pool"](tokens), "pool3": model.heads["pool3"](tokens),
                 "lin": model.heads["lin"](tokens.mean(dim=1))}
     sum(o.float().square().mean() for o in outs.values()).backward()
+    with torch.no_grad(), ac:   # diagnostics: forward_attention_weights (no RoPE in it) and the pooling weights
+        weights = {k: v.clone() for k, v in model.forward_attention_weights(x).items()}
+        weights["pool3"] = model.heads["pool3"].forward_weights(tokens.detach()).clone()
     d = plain_cfg(cfg)
     d["heads"] = {"pool": dict(out_features=10, num_queries=1), "pool3": dict(out_features=6, num_queries=3),
                   "lin": dict(out_features=5)}
     fix = {"cfg": d, "mode": mode, "state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "x": x,
-           "outs": {k: v.detach().clone() for k, v in outs.items()}, "x_grad": xg.grad.clone(),
+           "outs": {k: v.detach().clone() for k, v in outs.items()}, "weights": weights, "x_grad": xg.grad.clone(),
            "grads": {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}}
     path = os.path.join(OUT, name + ".pt")
     torch.save(fix, path)

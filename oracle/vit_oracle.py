@@ -358,6 +358,49 @@ def cross_attention(cfg: OracleConfig, sd: dict, pre: str, q: Tensor, kv: Tensor
     return F.dropout(o, p=hidden_dropout, training=training)
 
 
+def self_attention_weights(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, rope: Tensor | None = None) -> Tensor:
+    """attention_weights_qkv_packed, vit/attention.py:281-321."""
+    q, k, _ = project_qkv(cfg, sd, pre, x, rope)
+    return (q @ k.mT * (cfg.head_dim ** -0.5)).softmax(dim=-1)
+
+
+def vit_attention_weights(cfg: OracleConfig, sd: dict, x: Tensor) -> dict:
+    """ViT.forward_attention_weights, vit/vit.py:575-596."""
+    ln = cfg.norm_type == "layernorm"
+    dims = tuple(s // q for s, q in zip(x.shape[2:], cfg.patch_size))
+    x = patch_embed(cfg, sd, x, False)
+    if cfg.patch_embed_normalization:
+        x = apply_norm(x, sd["patch_embed_norm.weight"], sd.get("patch_embed_norm.bias"), None, ln)
+    B = x.shape[0]
+    x = torch.cat([sd["cls_tokens"].expand(B, -1, -1), sd["register_tokens"].expand(B, -1, -1), x], dim=1)
+    out = {}
+    for i in range(cfg.depth):
+        w = self_attention_weights(cfg, sd, f"blocks.{i}.self_attention.", x)
+        Bw, H, Lq, _ = w.shape
+        out[f"layer_{i}"] = w[..., cfg.num_register_tokens:].reshape(Bw, H, Lq, *dims).contiguous()
+        x = encoder_layer(cfg, sd, i, x, None, False)
+    return out
+
+
+def attentive_pool_weights(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, num_heads: int) -> Tensor:
+    """AttentivePool.forward_weights -> attention_weights_q_kv_packed, vit/attention.py:324-373, :658-659."""
+    ln = cfg.norm_type == "layernorm"
+    cp = pre + "cross_attention."
+    D = x.shape[-1]
+    dh = D // num_heads
+    q = sd[pre + "query"].expand(x.shape[0], -1, -1)
+    qn = apply_norm(q, sd[cp + "norm.weight"], sd.get(cp + "norm.bias"), 1e-5, ln)
+    qp = F.linear(qn, sd[cp + "q_proj.weight"], sd.get(cp + "q_proj.bias"))
+    k, _ = F.linear(x, sd[cp + "kv_proj.weight"], sd.get(cp + "kv_proj.bias")).chunk(2, dim=-1)
+    B, Lq, _ = qp.shape
+    qp = qp.view(B, Lq, -1, dh).transpose(1, 2)
+    k = k.view(B, k.shape[1], -1, dh).transpose(1, 2)
+    if cfg.qk_normalization:
+        qp = apply_norm(qp, sd[cp + "q_norm.weight"], sd.get(cp + "q_norm.bias"), 1e-5, ln)
+        k = apply_norm(k, sd[cp + "k_norm.weight"], sd.get(cp + "k_norm.bias"), 1e-5, ln)
+    return (qp @ k.mT * (dh ** -0.5)).softmax(dim=-1)
+
+
 def decoder_layer(cfg: OracleConfig, sd: dict, pre: str, x: Tensor, kv: Tensor, training: bool, self_attn: bool,
                   rope_q: Tensor | None = None, rope_k: Tensor | None = None) -> Tensor:
     """TransformerDecoderLayer.forward (vit/transformer.py:262-284) when ``self_attn``, else

@@ -120,6 +120,17 @@ def test_heads_golden_fixture(name):
     for k, g in fix["grads"].items():
         assert grads[k].dtype == g.dtype, k
         close(grads[k], g, grtol, k, atol_scale=2.0)
+    # attention probabilities: ViT.forward_attention_weights and AttentivePool.forward_weights
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "autocast_bf16"):
+        w = model.forward_attention_weights(fix["x"].to(DEV))
+        w["pool3"] = model.heads["pool3"].forward_weights(model(fix["x"].to(DEV)).visual_tokens)
+    assert set(w) == set(fix["weights"])
+    for k, v in fix["weights"].items():
+        # the fixture ran under CPU autocast, where softmax stays bf16; CUDA autocast runs softmax in fp32
+        assert w[k].shape == v.shape and (w[k].dtype == v.dtype or mode == "autocast_bf16"), k
+        close(w[k], v, rtol, k)
+    rows = w["pool3"].float().sum(-1)   # a probability row per query
+    torch.testing.assert_close(rows, torch.ones_like(rows), rtol=1e-2, atol=1e-2)
 
 
 @pytest.mark.parametrize("name", layer_golden_names())

@@ -74,6 +74,17 @@ def test_oracle_heads_match_reference_fixture(name):
     assert set(got) == set(fix["grads"])
     for k, g in fix["grads"].items():
         torch.testing.assert_close(got[k], g, **t, msg=lambda m, k=k: f"{k}: {m}")
+    # attention probabilities (vit/vit.py:575-596, vit/attention.py:658-659)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=fix["mode"] == "autocast_bf16"):
+        sd = fix["state"]
+        w = O.vit_attention_weights(cfg, sd, fix["x"])
+        feats = O.vit_forward(cfg, sd, fix["x"], training=False)
+        w["pool3"] = O.attentive_pool_weights(cfg, sd, "heads.pool3.pool.",
+                                              feats[:, cfg.num_cls_tokens + cfg.num_register_tokens:], cfg.num_attention_heads)
+    assert set(w) == set(fix["weights"])
+    for k, v in fix["weights"].items():
+        assert w[k].dtype == v.dtype and w[k].shape == v.shape, k
+        torch.testing.assert_close(w[k], v, **t, msg=lambda m, k=k: f"{k}: {m}")
 
 
 @pytest.mark.parametrize("name", layer_golden_names())

@@ -91,6 +91,15 @@ class SelfAttention(nn.Module):
         return (self.q_norm.weight, get_norm_bias(self.q_norm), self.k_norm.weight, get_norm_bias(self.k_norm),
                 self.q_norm.eps or 1e-5)
 
+    def forward_weights(self, x: Tensor, rope: Optional[Tensor] = None) -> Tensor:
+        """Attention probabilities [B, H, S, S] (vit/attention.py:455-477)."""
+        qw, qb, kw_, kb, qk_eps = self._qk_norm_inputs()
+        opt = _sublayer_opts(head_dim=self._head_dim, eps=self.norm.eps or 1e-5, layernorm=self._use_layer_norm,
+                             attention_dropout=0.0, dropout=0.0, training=False, residual=False, qk_eps=qk_eps,
+                             qk_layernorm=self._use_layer_norm)
+        return ops.self_attention_weights(x, self.norm.weight, get_norm_bias(self.norm), self.qkv_proj.weight,
+                                          self.qkv_proj.bias, qw, qb, kw_, kb, rope, opt)
+
     def forward(self, x: Tensor, attn_mask: Optional[Tensor] = None, rope: Optional[Tensor] = None) -> Tensor:
         return attention_qkv_packed(
             x, self.qkv_proj.weight, self.qkv_proj.bias, self.norm.weight, get_norm_bias(self.norm), self._use_layer_norm,
@@ -178,8 +187,16 @@ class CrossAttention(nn.Module):
             attn_mask, self.norm.eps or 1e-5, qw, qb, kw_, kb, self._use_layer_norm, qk_eps, self._qk_normalization,
             self.attention_dropout.p, self.dropout.p, self.training, rope_q, rope_k)
 
-    def forward_weights(self, *args, **kwargs):
-        raise NotImplementedError("vit_amd: attention-weight visualisation is not built")
+    def forward_weights(self, q: Tensor, kv: Tensor, rope_q: Optional[Tensor] = None,
+                        rope_k: Optional[Tensor] = None) -> Tensor:
+        """Attention probabilities [B, H, Lq, Lk] (vit/attention.py:568-592)."""
+        qw, qb, kw_, kb, qk_eps = self._qk_norm_inputs()
+        opt = _sublayer_opts(head_dim=self._head_dim, eps=self.norm.eps or 1e-5, layernorm=self._use_layer_norm,
+                             attention_dropout=0.0, dropout=0.0, training=False, residual=False, qk_eps=qk_eps,
+                             qk_layernorm=self._use_layer_norm)
+        return ops.cross_attention_weights(q, kv, self.norm.weight, get_norm_bias(self.norm), self.q_proj.weight,
+                                           self.q_proj.bias, self.kv_proj.weight, self.kv_proj.bias, qw, qb, kw_, kb,
+                                           rope_q, rope_k, opt)
 
 
 class AttentivePool(nn.Module):
@@ -210,4 +227,5 @@ class AttentivePool(nn.Module):
         return y.squeeze(1) if y.shape[1] == 1 else y
 
     def forward_weights(self, x: Tensor) -> Tensor:
-        raise NotImplementedError("vit_amd: attention-weight visualisation is not built")
+        """[B, H, num_queries, L] (vit/attention.py:658-659)."""
+        return self.cross_attention.forward_weights(self.query.expand(x.shape[0], -1, -1), x)

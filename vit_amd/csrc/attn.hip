@@ -250,6 +250,46 @@ __global__ __launch_bounds__(256) void attn_dkdv_simple_k(AttnP p) {
   }
 }
 
+// attention probabilities softmax(scale * q k^T) written out as [B, H, S, Sk] fp32 (diagnostics: the reference's
+// forward_weights).  One wave per query row; lane l owns keys l, l + 64, ...: raw scores go to the output row first, then
+// the same lanes normalise their own entries in place.
+template <class T>
+__global__ __launch_bounds__(256) void attn_weights_k(AttnP p, float* __restrict__ w) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Dh = (int)p.Dh, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t total = p.B * p.H * p.S;
+  const bool valid = row < total;
+  const int64_t r = valid ? row : 0;
+  const int64_t s = r % p.S, h = (r / p.S) % p.H, b = r / (p.S * p.H);
+  float* qs = sm + wv * Dh;
+  const T* qp = (const T*)p.q + b * p.q_sb + h * p.q_sh + s * p.q_ss;
+  for (int d = lane; d < Dh; d += 64) qs[d] = to_f<T>(qp[d]);
+  __syncthreads();
+  if (!valid) return;
+  const T* kp = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  float* out = w + r * p.Sk;
+  float m = -INFINITY;
+  for (int64_t j = lane; j < p.Sk; j += 64) {
+    float acc = 0.f;
+    for (int d = 0; d < Dh; d++) acc = fmaf(qs[d], to_f<T>(kp[j * p.k_ss + d]), acc);
+    acc *= p.scale;
+    out[j] = acc;
+    m = fmaxf(m, acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float l = 0.f;
+  for (int64_t j = lane; j < p.Sk; j += 64) {
+    const float e = expf(out[j] - m);
+    out[j] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  const float inv = 1.f / l;
+  for (int64_t j = lane; j < p.Sk; j += 64) out[j] *= inv;
+}
+
 // ================================================================================================
 // MFMA kernels
 // ================================================================================================
@@ -936,5 +976,20 @@ extern "C" int vitk_attn_bwd(const VitkAttn* a, void* stream) {
     }
   }
   VITK_LAUNCH_CHECK("attn_bwd");
+  return 0;
+}
+
+extern "C" int vitk_attn_weights(const VitkAttn* a, float* weights, void* stream) {
+  VITK_REQUIRE(a && a->q && a->k && weights, "attn_weights: null pointer");
+  VITK_REQUIRE(a->B >= 0 && a->H > 0 && a->S > 0 && a->Dh > 0 && a->Sk >= 0, "attn_weights: bad shape");
+  VITK_REQUIRE(a->dtype == VITK_F32 || a->dtype == VITK_BF16, "attn_weights: bad dtype");
+  if (a->B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const AttnP p = make_p(a);
+  const int64_t rows = a->B * a->H * a->S;
+  const size_t lds = (size_t)4 * a->Dh * sizeof(float);
+  if (a->dtype == VITK_F32) hipLaunchKernelGGL((attn_weights_k<float>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), lds, st, p, weights);
+  else hipLaunchKernelGGL((attn_weights_k<bf16>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), lds, st, p, weights);
+  VITK_LAUNCH_CHECK("attn_weights");
   return 0;
 }

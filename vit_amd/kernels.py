@@ -244,6 +244,23 @@ def attn_cross_bwd(q: Tensor, kv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, 
     return dq, dkv
 
 
+def attn_weights(q: Tensor, k: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: int, scale: float) -> Tensor:
+    """softmax(scale * q k^T) as [B, H, Sq, Sk] fp32.  q, k: 2-D views [B*Sq, >= H*Dh] / [B*Sk, >= H*Dh] whose rows hold
+    the heads side by side from column 0 of the view (row strides may exceed H*Dh: packed projections)."""
+    lib = L.load()
+    L.require_gpu(q, k)
+    assert q.dtype == k.dtype and q.stride(1) == 1 and k.stride(1) == 1
+    w = torch.empty((B, H, Sq, Sk), dtype=torch.float32, device=q.device)
+    a = L.VitkAttn()
+    a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), k.data_ptr(), None, None
+    a.B, a.H, a.S, a.Dh, a.Sk = B, H, Sq, Dh, Sk
+    a.q_sb, a.q_sh, a.q_ss = Sq * q.stride(0), Dh, q.stride(0)
+    a.kv_sb, a.kv_sh, a.kv_ss = Sk * k.stride(0), Dh, k.stride(0)
+    a.scale, a.dtype = scale, L.dt(q)
+    L.check(lib.vitk_attn_weights(C.byref(a), L.ptr(w), L.stream()))
+    return w
+
+
 def rope_qk_(qkv: Tensor, table_f32: Tensor, B: int, S: int, H: int, Dh: int, prefix: int, inverse: bool,
              emulate_bf16: bool) -> Tensor:
     lib = L.load()

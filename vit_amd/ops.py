@@ -460,6 +460,63 @@ class CrossAttentionFn(torch.autograd.Function):
                 None)
 
 
+def _weights_dtype(tc: torch.dtype) -> torch.dtype:
+    """dtype of (q @ k.mT * s).softmax(-1): softmax is on autocast's fp32 list, otherwise the operands' dtype."""
+    return torch.float32 if torch.is_autocast_enabled("cuda") else tc
+
+
+@torch.no_grad()
+def self_attention_weights(x, norm_w, norm_b, w_qkv, b_qkv, qn_w, qn_b, kn_w, kn_b, rope, opt) -> Tensor:
+    """Attention probabilities [B, H, S, S] of a self-attention layer (vit/attention.py:281-321)."""
+    L.require_gpu(x, norm_w, w_qkv)
+    B, S, D = x.shape
+    Dh = opt["head_dim"]
+    H = D // Dh
+    tc = compute_dtype(w_qkv.dtype)
+    M = B * S
+    xn, _, _ = K.norm_fwd(x.reshape(M, D).contiguous(), norm_w, norm_b, opt["eps"], opt["layernorm"], tc)
+    qkv = torch.empty((M, 3 * D), dtype=tc, device=x.device)
+    K.gemm(xn, _cast(w_qkv, tc), trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=_cast(b_qkv, tc))
+    if qn_w is not None:
+        for which, (w_, b_) in enumerate(((qn_w, qn_b), (kn_w, kn_b))):
+            pre = qkv[:, which * D:(which + 1) * D].contiguous().view(M * H, Dh)
+            nrm, _, _ = K.norm_fwd(pre, w_, b_, opt["qk_eps"], opt["qk_layernorm"], tc)
+            qkv[:, which * D:(which + 1) * D].copy_(nrm.view(M, D))
+    table, emu = _rope_table(rope, None, B, B, tc)
+    if table is not None:
+        K.rope_qk_(qkv, table, B, S, H, Dh, S - table.shape[-2], False, emu)
+    return K.attn_weights(qkv[:, :D], qkv[:, D:2 * D], B, S, S, H, Dh, Dh ** -0.5).to(_weights_dtype(tc))
+
+
+@torch.no_grad()
+def cross_attention_weights(q, kv, norm_w, norm_b, w_q, b_q, w_kv, b_kv, qn_w, qn_b, kn_w, kn_b, rope_q, rope_k, opt) -> Tensor:
+    """Attention probabilities [B, H, Lq, Lk] of a cross-attention layer (vit/attention.py:324-373)."""
+    L.require_gpu(q, kv, norm_w, w_q, w_kv)
+    B, Lq, D = q.shape
+    Lk = kv.shape[1]
+    Dh = opt["head_dim"]
+    H = D // Dh
+    tc = compute_dtype(w_q.dtype)
+    Mq, Mk = B * Lq, B * Lk
+    qn, _, _ = K.norm_fwd(q.reshape(Mq, D).contiguous(), norm_w, norm_b, opt["eps"], opt["layernorm"], tc)
+    qp = torch.empty((Mq, D), dtype=tc, device=q.device)
+    K.gemm(qn, _cast(w_q, tc), trans_a=False, trans_b=False, M=Mq, N=D, K=D, out=qp, bias=_cast(b_q, tc))
+    kvp = torch.empty((Mk, 2 * D), dtype=tc, device=q.device)
+    K.gemm(_cast(kv.reshape(Mk, D), tc), _cast(w_kv, tc), trans_a=False, trans_b=False, M=Mk, N=2 * D, K=D, out=kvp,
+           bias=_cast(b_kv, tc))
+    if qn_w is not None:
+        qp = K.norm_fwd(qp.view(Mq * H, Dh), qn_w, qn_b, opt["qk_eps"], opt["qk_layernorm"], tc)[0].view(Mq, D)
+        nk = K.norm_fwd(kvp[:, :D].contiguous().view(Mk * H, Dh), kn_w, kn_b, opt["qk_eps"], opt["qk_layernorm"], tc)[0]
+        kvp[:, :D].copy_(nk.view(Mk, D))
+    tq, emu_q = _rope_table(rope_q, None, B, B, tc)
+    tk, emu_k = _rope_table(rope_k, None, B, B, tc)
+    if tq is not None:
+        K.rope_rows_(qp, tq, B, Lq, H, Dh, False, emu_q)
+    if tk is not None:
+        K.rope_rows_(kvp, tk, B, Lk, H, Dh, False, emu_k)
+    return K.attn_weights(qp, kvp[:, :D], B, Lq, Lk, H, Dh, Dh ** -0.5).to(_weights_dtype(tc))
+
+
 class MlpSublayerFn(torch.autograd.Function):
     """x -> x (+) alpha * gamma * dropout(fc2(dropout(act(fc1(norm(x))))))   (vit/fused.py:96-166)."""
 

@@ -4,8 +4,7 @@ forward signature; every arithmetic step of forward/backward runs in libvitk ker
 Token masks (masked pre-training) drop tokens ahead of the blocks and give every sample its own RoPE rows.
 Heads: the linear head and the attentive-pool head (vit_amd/head.py).
 Decoder / cross-attention layers of the backbone's width: create_decoder_layer, create_cross_attention_layer.
-Not provided (outside the encoder hot path): dense-prediction heads,
-attention-weight visualisation, torchao quantization.  They raise NotImplementedError rather than fall back."""
+Not provided (outside the encoder hot path): dense-prediction heads, torchao quantization.  They raise NotImplementedError rather than fall back."""
 from __future__ import annotations
 
 from typing import Any, Optional, Sequence
@@ -166,6 +165,22 @@ class ViT(nn.Module):
         if output_norm:
             x = self.output_norm(x)
         return ViTFeatures(x, c.num_register_tokens, c.num_cls_tokens, grid)
+
+    @torch.no_grad()
+    def forward_attention_weights(self, x: Tensor) -> dict:
+        """Per-layer attention probabilities of every token over the visual tokens, laid out on the token grid:
+        {"layer_i": [B, H, S, *grid]} (vit/vit.py:575-596; like the reference, without RoPE)."""
+        grid = self.stem.tokenized_size(x.shape[2:])
+        x = self.stem(x)
+        x = self.normalize_patch_embeddings(x)
+        x = self.add_prefix_tokens(x)
+        weights = {}
+        for i, block in enumerate(self.blocks):
+            w = block.self_attention.forward_weights(x)
+            B, H, Lq, Lk = w.shape
+            weights[f"layer_{i}"] = w[..., self._config.num_register_tokens:].reshape(B, H, Lq, *grid).contiguous()
+            x = block(x)
+        return weights
 
     # ---- trainability switches -----------------------------------------------------------------------
     def mlp_requires_grad_(self, requires_grad: bool = True) -> None:

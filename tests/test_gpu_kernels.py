@@ -407,3 +407,32 @@ def test_fused_activation_epilogues_equal_the_unfused_kernels(glu, name, drop):
     assert torch.equal(h == 0, h_ref == 0) or drop == 0.0
     close(h, h_ref, 8e-3, 1e-3)
     close(dp, dp_ref, 8e-3, 1e-3)
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_standalone_apply_rope_matches_reference_vectors(tag):
+    """vit_amd.rope.apply_rope on [B, H, S, Dh] against the reference's own apply_rope outputs (g07_ops), and its
+    backward against autograd through the oracle's restatement."""
+    from conftest import load_golden
+    from oracle import vit_oracle as O
+    from vit_amd.rope import apply_rope
+
+    fix = load_golden("g07_ops")
+    q, table = fix[f"rope_q_{tag}"].to(DEV), fix[f"rope_table_{tag}"].to(DEV)
+    out = apply_rope(q, table)
+    assert out.dtype == q.dtype
+    if tag == "bf16":   # every product and the sum rounded like eager bf16 arithmetic: the same bits
+        assert torch.equal(out.cpu(), fix[f"rope_out_{tag}"])
+        mixed = apply_rope(q, fix["rope_table_fp32"].to(DEV))
+        torch.testing.assert_close(mixed.cpu().float(), fix["rope_out_bf16_x_fp32_table"].float(), rtol=2e-2, atol=2e-2)
+    else:               # fp32: the kernel contracts x1*c - x2*s into an fma
+        torch.testing.assert_close(out.cpu(), fix[f"rope_out_{tag}"], rtol=1e-5, atol=1e-6)
+    x = q.float().clone().requires_grad_(True)
+    t32 = fix["rope_table_fp32"].to(DEV)
+    g = torch.randn_like(x)
+    (apply_rope(x, t32) * g).sum().backward()
+    xr = q.float().clone().requires_grad_(True)
+    (O.apply_rope(xr, t32) * g).sum().backward()
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-5, atol=1e-6)
+    per = torch.stack([t32, t32.flip(1)], 1)[:, :, None]   # [2, B=2, 1, N, Dh]
+    torch.testing.assert_close(apply_rope(q.float(), per), O.apply_rope(q.float(), per), rtol=1e-5, atol=1e-6)

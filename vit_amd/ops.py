@@ -517,6 +517,40 @@ def cross_attention_weights(q, kv, norm_w, norm_b, w_q, b_q, w_kv, b_kv, qn_w, q
     return K.attn_weights(qp, kvp[:, :D], B, Lq, Lk, H, Dh, Dh ** -0.5).to(_weights_dtype(tc))
 
 
+class RopeFn(torch.autograd.Function):
+    """apply_rope on a [B, H, S, Dh] tensor (vit/rope.py:139-163): the last N rows of every head are rotated, computed in
+    the table's dtype and cast back; the backward is the transposed rotation."""
+
+    @staticmethod
+    def forward(ctx, x, rope):
+        L.require_gpu(x, rope)
+        B, H, S, Dh = x.shape
+        work = rope.dtype   # x.type_as(rope): the rotation is computed in the table's dtype
+        emu = rope.dtype == torch.bfloat16
+        if rope.dim() == 5:   # [2, B, 1, N, Dh] -> one table per (sample, head) row block
+            table = rope.detach()[:, :, 0].to(torch.float32)[:, :, None].expand(2, B, H, -1, Dh).reshape(2, B * H, -1, Dh)
+        else:
+            table = rope.detach().to(torch.float32)
+        table = table.contiguous()
+        y = x.detach().to(work).contiguous().view(B * H * S, Dh).clone()
+        K.rope_rows_(y, table, B * H, S, 1, Dh, False, emu)
+        ctx.save_for_backward(table)
+        ctx.meta = (B, H, S, Dh, emu, work, x.dtype)
+        return y.view(B, H, S, Dh).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (table,) = ctx.saved_tensors
+        B, H, S, Dh, emu, work, xdtype = ctx.meta
+        g = dy.to(work).contiguous().view(B * H * S, Dh).clone()
+        K.rope_rows_(g, table, B * H, S, 1, Dh, True, emu)
+        return g.view(B, H, S, Dh).to(xdtype), None
+
+
+def apply_rope(x: Tensor, rope: Tensor) -> Tensor:
+    return RopeFn.apply(x, rope)
+
+
 class MlpSublayerFn(torch.autograd.Function):
     """x -> x (+) alpha * gamma * dropout(fc2(dropout(act(fc1(norm(x))))))   (vit/fused.py:96-166)."""
 

@@ -68,3 +68,11 @@ class RopePositionEmbedding(nn.Module):
             coords *= torch.empty(1, **dd).uniform_(-r, r, generator=gen).exp()
         ang = (2 * math.pi * coords[:, :, None] / self.periods[None, None, :]).flatten(1, 2).tile(2)
         return torch.stack([torch.sin(ang), torch.cos(ang)], dim=0)
+
+
+def apply_rope(x: Tensor, rope: Tensor) -> Tensor:
+    """Rotate the last ``rope.shape[-2]`` rows of x [B, H, S, Dh] with the table [2, N, Dh] (or the per-sample
+    [2, B, 1, N, Dh]); rows before them (prefix tokens) pass through (vit/rope.py:139-163)."""
+    from . import ops
+
+    return ops.apply_rope(x, rope)

@@ -52,6 +52,11 @@ CASES = {
                                               layer_scale=0.1), 8, (32, 32), "fp32"),
     "g11_masked_rope_droppath_fp32": (dict(activation="srelu", pos_enc="rope", drop_path_rate=0.25), 8, (32, 32), "fp32"),
 }
+# volumetric input (PatchEmbed3d, vit/patch_embed.py:62-109); depth 18 leaves two slices no patch covers
+CASES["g14_patch3d_fourier_fp32"] = (dict(activation="swiglu", pos_enc="fourier", patch_size=(4, 8, 8), img_size=(16, 32, 32),
+                                          num_register_tokens=2), 2, (18, 32, 32), "fp32")
+CASES["g14_patch3d_learnable_autocast"] = (dict(activation="srelu", pos_enc="learnable", patch_size=(4, 8, 8), img_size=(16, 32, 32),
+                                                num_cls_tokens=1), 2, (16, 32, 32), "autocast_bf16")
 MASKED = {k for k in CASES if k.startswith("g11_masked")}
 
 

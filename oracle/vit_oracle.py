@@ -281,9 +281,10 @@ def encoder_layer(cfg: OracleConfig, sd: dict, i: int, x: Tensor, rope: Tensor |
 
 
 def patch_embed(cfg: OracleConfig, sd: dict, x: Tensor, training: bool) -> Tensor:
-    """vit/patch_embed.py:52-59."""
+    """vit/patch_embed.py:52-59 (2-D) and :101-109 (3-D)."""
     p = tuple(cfg.patch_size)
-    y = F.conv2d(x, sd["stem.patch.weight"], sd.get("stem.patch.bias"), stride=p).flatten(2).transpose(1, 2)
+    conv = F.conv2d if len(p) == 2 else F.conv3d
+    y = conv(x, sd["stem.patch.weight"], sd.get("stem.patch.bias"), stride=p).flatten(2).transpose(1, 2)
     dims = tuple(s // q for s, q in zip(x.shape[2:], p))
     if cfg.pos_enc == "fourier":
         return y + fourier_position(dims, sd["stem.pos_enc.w_fourier"], sd["stem.pos_enc.w_fc1.weight"],

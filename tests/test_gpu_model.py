@@ -49,7 +49,7 @@ def run_train(model, x, autocast, seed, loss="square_mean", mask=None):
 
 # g03 trains with dropout on the learnable position table (CPU RNG stream of the fixture cannot be replayed on
 # the GPU).
-TRAIN_SKIP = {"g03_layernorm_gelu_learnable_cls_fp32"}
+TRAIN_SKIP = {"g03_layernorm_gelu_learnable_cls_fp32", "g14_patch3d_learnable_autocast"}
 # These draw the drop-path subset with torch.randperm on the CPU generator in the fixture; the GPU generator
 # draws a different permutation, so the train pass is compared against the oracle on the GPU instead.
 RANDPERM = {"g04_droppath_layerscale_fp32", "g11_masked_fourier_droppath_fp32", "g11_masked_rope_droppath_fp32"}

@@ -143,8 +143,10 @@ def test_rope_table_host_code_matches_reference_vectors():  # vit/rope.py:60-136
 def test_unsupported_features_fail_loudly():
     with pytest.raises(NotImplementedError):
         small(heads={"cls": object()}).instantiate()
-    with pytest.raises(NotImplementedError):
-        small(patch_size=(4, 4, 4), img_size=(8, 8, 8)).instantiate()
+    with pytest.raises(ValueError):
+        small(patch_size=(4, 4, 4, 4), img_size=(8, 8, 8, 8)).instantiate()
+    vol = small(patch_size=(4, 4, 4), img_size=(8, 8, 8)).instantiate()   # volumetric stem: Conv3d parameter holder
+    assert vol.stem.patch.weight.dim() == 5 and vol.stem.tokenized_size((8, 8, 8)) == (2, 2, 2)
 
 
 def test_forward_on_cpu_raises_instead_of_falling_back():

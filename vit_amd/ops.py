@@ -651,8 +651,11 @@ class MlpSublayerFn(torch.autograd.Function):
 # patch embedding: Conv2d(k = stride = patch) as im2col + GEMM, "+ pos" in the epilogue (vit/patch_embed.py:52-59)
 # ------------------------------------------------------------------------------------------------
 class PatchEmbedFn(torch.autograd.Function):
+    """``fold`` > 1: x holds ``fold`` depth slabs per sample as consecutive batch entries (3-D patches with the depth
+    offsets folded into the channels); the position table then covers fold * gh * gw tokens per sample."""
+
     @staticmethod
-    def forward(ctx, x, w, b, pos):
+    def forward(ctx, x, w, b, pos, fold):
         L.require_gpu(x, w)
         tc = compute_dtype(w.dtype)
         B, Cc, H, W = x.shape
@@ -665,18 +668,19 @@ class PatchEmbedFn(torch.autograd.Function):
         wc = torch.zeros((D, Kp), dtype=tc, device=x.device)
         wc[:, :Kc] = w.detach().reshape(D, Kc)
         bc = _cast(b, tc)
-        posc = None if pos is None else _cast(pos.reshape(N, D), tc)
+        posc = None if pos is None else _cast(pos.reshape(N * fold, D), tc)
         y = torch.empty((B * N, D), dtype=tc, device=x.device)
         K.gemm(cols, wc, trans_a=False, trans_b=False, M=B * N, N=D, K=Kp, out=y, bias=bc, epilogue=L.EPI_PATCH, pos=posc,
-               tokens=N, seq=N, prefix=0)
+               tokens=N * fold, seq=N * fold, prefix=0)
         ctx.save_for_backward(cols, wc)
-        ctx.meta = (x.shape, w.shape, x.dtype, w.dtype, tc, N, Kc, Kp, b is not None, None if pos is None else (pos.shape, pos.dtype))
-        return y.view(B, N, D)
+        ctx.meta = (x.shape, w.shape, x.dtype, w.dtype, tc, N, Kc, Kp, b is not None, None if pos is None else (pos.shape, pos.dtype),
+                    fold)
+        return y.view(B // fold, N * fold, D)
 
     @staticmethod
     def backward(ctx, dy):
         cols, wc = ctx.saved_tensors
-        xshape, wshape, xdtype, wdtype, tc, N, Kc, Kp, has_b, posinfo = ctx.meta
+        xshape, wshape, xdtype, wdtype, tc, N, Kc, Kp, has_b, posinfo, fold = ctx.meta
         need = ctx.needs_input_grad
         B = xshape[0]
         D = wshape[0]
@@ -688,12 +692,12 @@ class PatchEmbedFn(torch.autograd.Function):
         if dcols is not None:
             dx = K.col2im(dcols, xshape, wshape[2], wshape[3], xdtype)
         if posinfo is not None and need[3]:
-            dpos = K.colsum(dy2, B, N * D, N * D, posinfo[1]).view(posinfo[0])
-        return dx, dw, db, dpos
+            dpos = K.colsum(dy2, B // fold, N * fold * D, N * fold * D, posinfo[1]).view(posinfo[0])
+        return dx, dw, db, dpos, None
 
 
-def patch_embed(x: Tensor, weight: Tensor, bias: Optional[Tensor], pos: Optional[Tensor]) -> Tensor:
-    return PatchEmbedFn.apply(x, weight, bias, pos)
+def patch_embed(x: Tensor, weight: Tensor, bias: Optional[Tensor], pos: Optional[Tensor], fold: int = 1) -> Tensor:
+    return PatchEmbedFn.apply(x, weight, bias, pos, fold)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ from .features import ViTFeatures
 from .head import AttentivePoolHeadConfig, HeadConfig
 from .initialization import trunc_normal_
 from .norm import make_norm
-from .patch_embed import PatchEmbed2d
+from .patch_embed import PatchEmbed2d, PatchEmbed3d
 from .rope import RopePositionEmbedding
 from .tokens import apply_mask, create_mask
 from .transformer import CrossAttentionTransformer, TransformerDecoderLayer, TransformerEncoderLayer
@@ -32,8 +32,8 @@ class ViT(nn.Module):
     def __init__(self, config: ViTConfig, mlp_quantization_config: Any = None, qkv_quantization_config: Any = None,
                  attn_quantization_config: Any = None, device: Optional[torch.device] = None):
         super().__init__()
-        if len(config.patch_size) != 2:
-            raise NotImplementedError("vit_amd: only 2-D patch embedding is on the hot path (PatchEmbed3d is not built)")
+        if len(config.patch_size) not in (2, 3):
+            raise ValueError(f"patch_size must have 2 or 3 entries, got {config.patch_size}")
         for name, head_config in config.heads.items():
             if not isinstance(head_config, (HeadConfig, AttentivePoolHeadConfig)):
                 raise NotImplementedError(f"vit_amd: head {name!r} ({type(head_config).__name__}) is not built; "
@@ -43,7 +43,8 @@ class ViT(nn.Module):
         kw = {"device": device, "dtype": config.dtype}
         self._config = config
         D = config.hidden_size
-        self.stem = PatchEmbed2d(config.in_channels, D, config.patch_size, config.img_size,
+        stem_type = PatchEmbed2d if len(config.patch_size) == 2 else PatchEmbed3d
+        self.stem = stem_type(config.in_channels, D, config.patch_size, config.img_size,
                                  pos_enc="none" if config.pos_enc == "rope" else config.pos_enc, **kw)
         self.patch_embed_norm = make_norm(D, config.norm_type, **kw) if config.patch_embed_normalization else None
         self.rope = None

@@ -43,11 +43,12 @@ int vitk_norm_fwd(const void* x, int x_dtype, const void* w, const void* b, int 
 
 /* Backward of the above.  dx[row(r),:] = (add ? add[row(r),:] : 0) + d norm / d x.
  * dw/db (dtype w_dtype) are reduced over rows through `workspace` (fp32, vitk_norm_bwd_workspace_bytes(D)).
- * `add` may alias `dx`. dw/db may be NULL (frozen parameters). */
+ * `add` may alias `dx`. dw/db may be NULL (frozen parameters).  dx_bf16 (or NULL): a bf16 copy of the rows written to
+ * dx, for the consumer that multiplies this gradient in bf16 next (saves it a pass over the fp32 rows). */
 size_t vitk_norm_bwd_workspace_bytes(int64_t D);
 int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* w, int w_dtype,
                   const float* rstd, const float* mean, const void* add, void* dx, int dx_dtype, void* dw, void* db,
-                  const int64_t* row_idx, int64_t rows, int64_t D, int is_layernorm, void* workspace, void* stream);
+                  const int64_t* row_idx, int64_t rows, int64_t D, int is_layernorm, void* workspace, void* dx_bf16, void* stream);
 
 /* ---- GEMM: F.linear at vit/attention.py:93,213, vit/fused.py:114,117,153,164, the conv of
  *      vit/patch_embed.py:54 (as im2col GEMM), and their autograd backward (dgrad / wgrad) -------

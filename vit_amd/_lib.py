@@ -78,7 +78,7 @@ def load() -> C.CDLL:
     vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
     sigs = {
         "vitk_norm_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i64, i64, f32, i32, vp],
-        "vitk_norm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, vp],
+        "vitk_norm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, vp, vp],
         "vitk_gemm": [C.POINTER(VitkGemm), vp],
         "vitk_attn_fwd": [C.POINTER(VitkAttn), vp],
         "vitk_attn_bwd": [C.POINTER(VitkAttn), vp],

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
                                                   const TW* __restrict__ w, const float* __restrict__ rstd_in,
                                                   const float* __restrict__ mean_in, const TO* add, TO* dx,
                                                   const int64_t* __restrict__ row_idx, int64_t rows, int D,
-                                                  float* __restrict__ partial /* [grid][2][D] */, int want_dw) {
+                                                  float* __restrict__ partial /* [grid][2][D] */, int want_dw,
+                                                  bf16* __restrict__ shadow /* bf16 copy of the dx rows, or null */) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][2][D]
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -148,6 +149,12 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
           o.v[i] += rstd * (g - c1 - xh * c2);
         }
         o.store(outr + d);
+        if (shadow) {   // the next consumer multiplies this gradient in bf16: hand it the cast along with the fp32 rows
+          Vec4<bf16> sv;
+#pragma unroll
+          for (int i = 0; i < 4; i++) sv.v[i] = round_as<TO>(o.v[i]);
+          sv.store(shadow + src * D + d);
+        }
       }
     }
   }
@@ -341,11 +348,12 @@ extern "C" size_t vitk_norm_bwd_workspace_bytes(int64_t D) {
 template <class TG, class TX, class TW, class TO, bool LN>
 static int norm_bwd_launch(const void* dy, const void* x, const void* w, const float* rstd, const float* mean,
                            const void* add, void* dx, const int64_t* idx, int64_t rows, int D, float* ws, int want_dw,
-                           int grid, hipStream_t st) {
+                           int grid, hipStream_t st, void* shadow) {
   const size_t lds = want_dw ? (size_t)8 * D * sizeof(float) : 0;
 #define NB_LAUNCH(MAXIT)                                                                                            \
   hipLaunchKernelGGL((norm_bwd_k<TG, TX, TW, TO, LN, MAXIT>), dim3(grid), dim3(256), lds, st, (const TG*)dy,        \
-                     (const TX*)x, (const TW*)w, rstd, mean, (const TO*)add, (TO*)dx, idx, rows, D, ws, want_dw)
+                     (const TX*)x, (const TW*)w, rstd, mean, (const TO*)add, (TO*)dx, idx, rows, D, ws, want_dw,    \
+                     (bf16*)shadow)
   if (D <= 512) NB_LAUNCH(2);
   else if (D <= 1024) NB_LAUNCH(4);
   else if (D <= 2048) NB_LAUNCH(8);
@@ -357,7 +365,7 @@ static int norm_bwd_launch(const void* dy, const void* x, const void* w, const f
 extern "C" int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* w, int w_dtype,
                              const float* rstd, const float* mean, const void* add, void* dx, int dx_dtype, void* dw,
                              void* db, const int64_t* row_idx, int64_t rows, int64_t D, int is_layernorm, void* workspace,
-                             void* stream) {
+                             void* dx_bf16, void* stream) {
   VITK_REQUIRE(dy && x && w && rstd && dx, "norm_bwd: null pointer");
   VITK_REQUIRE(!is_layernorm || mean, "norm_bwd: LayerNorm needs the saved mean");
   VITK_REQUIRE(D > 0 && D % 4 == 0, "norm_bwd: D=%lld must be a positive multiple of 4", (long long)D);
@@ -379,10 +387,10 @@ extern "C" int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_
         DISPATCH_DTYPE(dx_dtype, TO, {
           if (is_layernorm)
             rc = norm_bwd_launch<TG, TX, TW, TO, true>(dy, x, w, rstd, mean, add, dx, row_idx, rows, (int)D,
-                                                       (float*)workspace, want_dw, grid, st);
+                                                       (float*)workspace, want_dw, grid, st, dx_bf16);
           else
             rc = norm_bwd_launch<TG, TX, TW, TO, false>(dy, x, w, rstd, mean, add, dx, row_idx, rows, (int)D,
-                                                        (float*)workspace, want_dw, grid, st);
+                                                        (float*)workspace, want_dw, grid, st, dx_bf16);
         });
       });
     });

@@ -72,13 +72,16 @@ def norm_fwd(x2: Tensor, w: Tensor, b: Optional[Tensor], eps: float, layernorm: 
 
 
 def norm_bwd(dy: Tensor, x2: Tensor, w: Tensor, rstd: Tensor, mean: Optional[Tensor], layernorm: bool,
-             add: Optional[Tensor], dx: Tensor, want_dw: bool, want_db: bool, row_idx: Optional[Tensor] = None):
-    """dx[row(r)] = (add[row(r)] if add is not None else 0) + dnorm/dx; returns (dw, db) in w.dtype."""
+             add: Optional[Tensor], dx: Tensor, want_dw: bool, want_db: bool, row_idx: Optional[Tensor] = None,
+             dx_bf16: Optional[Tensor] = None):
+    """dx[row(r)] = (add[row(r)] if add is not None else 0) + dnorm/dx; returns (dw, db) in w.dtype.
+    ``dx_bf16`` (same shape as dx, bfloat16) also receives the written rows cast to bf16."""
     lib = L.load()
     L.require_gpu(dy, x2, w, dx)
     dy, x2 = _c(dy), _c(x2)
     rows, D = dy.shape
     assert dx.is_contiguous() and (add is None or (add.is_contiguous() and add.dtype == dx.dtype))
+    assert dx_bf16 is None or (dx_bf16.dtype == torch.bfloat16 and dx_bf16.shape == dx.shape and dx_bf16.is_contiguous())
     dw = torch.empty_like(w) if want_dw else None
     db = torch.empty_like(w) if (want_db and layernorm) else None
     ws = _workspace(lib.vitk_norm_bwd_workspace_bytes(D), dy.device) if (dw is not None or db is not None) else None
@@ -86,7 +89,7 @@ def norm_bwd(dy: Tensor, x2: Tensor, w: Tensor, rstd: Tensor, mean: Optional[Ten
     dw_buf = dw if dw is not None else (torch.empty_like(w) if db is not None else None)
     L.check(lib.vitk_norm_bwd(L.ptr(dy), L.dt(dy), L.ptr(x2), L.dt(x2), L.ptr(_c(w)), L.dt(w), L.ptr(rstd), L.ptr(mean),
                               L.ptr(add), L.ptr(dx), L.dt(dx), L.ptr(dw_buf), L.ptr(db), L.ptr(row_idx), rows, D,
-                              int(layernorm), L.ptr(ws), L.stream()))
+                              int(layernorm), L.ptr(ws), L.ptr(dx_bf16), L.stream()))
     return dw, db
 
 

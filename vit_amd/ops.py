@@ -9,6 +9,7 @@ Dtype contract (what the reference's eager path produces, measured against it):
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -198,10 +199,41 @@ def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, 
     return out, aux
 
 
+# The gradient of the residual stream leaves one sub-layer's norm backward in fp32 and is the first thing the previous
+# sub-layer casts to bf16 (when there is no layer scale, drop-path or dropout to apply on the way).  The norm backward
+# kernel can write that cast next to the fp32 rows, which saves a pass over them.  One slot: the producer leaves
+# (fp32 rows, bf16 copy) here, the next _residual_grad takes the copy if it is handed the very same buffer; holding the
+# fp32 tensor keeps its memory from being reused for anything else in between.
+_SHADOW: list = [None]
+_SHADOW_ON = os.environ.get("VITK_NO_SHADOW", "") == ""
+
+
+def _shadow_buffer(dx: Tensor, tc: torch.dtype, rows: Optional[Tensor]) -> Optional[Tensor]:
+    if not _SHADOW_ON or rows is not None or dx.dtype != torch.float32 or tc != torch.bfloat16:
+        return None
+    return torch.empty(dx.shape, dtype=torch.bfloat16, device=dx.device)
+
+
+def _offer_shadow(dx: Tensor, shadow: Optional[Tensor]) -> None:
+    _SHADOW[0] = None if shadow is None else (dx, shadow)
+
+
+def _take_shadow(dnew2: Tensor) -> Optional[Tensor]:
+    entry, _SHADOW[0] = _SHADOW[0], None
+    if entry is None:
+        return None
+    src, shadow = entry
+    same = src.data_ptr() == dnew2.data_ptr() and src.shape == dnew2.shape and src.dtype == dnew2.dtype
+    return shadow if same else None
+
+
 def _residual_grad(dnew2: Tensor, tc: torch.dtype, gamma: Optional[Tensor], rows: Optional[Tensor], nrows: int, alpha: float,
                    drop_p: float, seed: int, aux: Optional[Tensor], need_dgamma: bool):
     """Gradient w.r.t. the linear's output, and w.r.t. gamma."""
     N = dnew2.shape[1]
+    shadow = _take_shadow(dnew2)
+    if shadow is not None and gamma is None and rows is None and alpha == 1.0 and drop_p == 0.0 and tc == torch.bfloat16:
+        return shadow, None
     dy = K.scale_cast(dnew2, nrows, N, tc, row_idx=rows, gamma=gamma, alpha=alpha, drop_p=drop_p, seed=seed)
     dgamma = None
     if gamma is not None and need_dgamma:
@@ -322,7 +354,10 @@ class AttentionSublayerFn(torch.autograd.Function):
         else:
             dx = torch.zeros_like(x2) if rows is not None else torch.empty_like(x2)
             add = None
-        dnw, dnb = K.norm_bwd(dxn, x2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dx, need[1], has_nb and need[2], rows)
+        shadow = _shadow_buffer(dx, tc, rows) if residual else None
+        dnw, dnb = K.norm_bwd(dxn, x2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dx, need[1], has_nb and need[2], rows,
+                              dx_bf16=shadow)
+        _offer_shadow(dx, shadow)
         dx = dx.view(B, S, D)
         if dx.dtype != xdtype:
             dx = dx.to(xdtype)
@@ -633,8 +668,10 @@ class MlpSublayerFn(torch.autograd.Function):
             else:
                 dx = torch.zeros_like(x2) if rows is not None else torch.empty_like(x2)
                 add = None
+            shadow = _shadow_buffer(dx, tc, rows) if residual else None
             dnw, dnb = K.norm_bwd(dxn, x2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dx, need[1],
-                                  has_nb and need[2], rows)
+                                  has_nb and need[2], rows, dx_bf16=shadow)
+            _offer_shadow(dx, shadow)
         else:
             dx = dxn.to(x2.dtype)
             if residual:

@@ -332,6 +332,30 @@ def test_masked_tokens_with_drop_path_match_oracle_fp32(pos_enc):
     compare_with_oracle_on_gpu(cfg, 8, (32, 48), False, 1e-4, oracle_device="cuda", keep_ratio=0.5)
 
 
+def test_ragged_mask_pads_short_samples_fp32():
+    """Samples that keep fewer tokens are padded at the end with zero tokens and zero RoPE rows (vit/tokens.py:36-55 with
+    padding_value 0): same output and gradients as the oracle, for RoPE and for Fourier positions."""
+    for pos_enc in ("rope", "fourier"):
+        cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 48), depth=2, hidden_size=64, ffn_hidden_size=128,
+                        num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="srelu", pos_enc=pos_enc,
+                        num_register_tokens=1, dtype=torch.float32)
+        model = cfg.instantiate(device=DEV)
+        sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=5), seed=6)
+        model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(3, 3, 32, 48, generator=g)
+        mask = torch.zeros(3, 24, dtype=torch.bool)
+        for b, keep in enumerate((24, 7, 13)):
+            mask[b, torch.randperm(24, generator=g)[:keep]] = True
+        out, xg, grads = run_train(model, x.to(DEV), False, 1, mask=mask.to(DEV))
+        ref = O.run_fwd_bwd(oracle_cfg(cfg), sd, x, training=True, seed=1, mask=mask)
+        assert out.shape == ref["out"].shape == (3, 25, 64)
+        close(out, ref["out"], 1e-4, "out")
+        close(xg, ref["x_grad"], 1e-4, "x_grad", atol_scale=2.0)
+        for k, gr in ref["grads"].items():
+            close(grads[k], gr, 1e-4, k, atol_scale=2.0)
+
+
 @pytest.mark.parametrize("mode", ["autocast", "bf16"])
 def test_masked_tokens_match_oracle_bf16(mode):
     cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(64, 64), depth=2, hidden_size=128, ffn_hidden_size=256,

@@ -223,7 +223,8 @@ def _take_shadow(dnew2: Tensor) -> Optional[Tensor]:
     if entry is None:
         return None
     src, shadow = entry
-    same = src.data_ptr() == dnew2.data_ptr() and src.shape == dnew2.shape and src.dtype == dnew2.dtype
+    same = (src.device == dnew2.device and src.data_ptr() == dnew2.data_ptr() and src.shape == dnew2.shape
+            and src.dtype == dnew2.dtype)
     return shadow if same else None
 
 

@@ -235,7 +235,10 @@ def _residual_grad(dnew2: Tensor, tc: torch.dtype, gamma: Optional[Tensor], rows
     shadow = _take_shadow(dnew2)
     if shadow is not None and gamma is None and rows is None and alpha == 1.0 and drop_p == 0.0 and tc == torch.bfloat16:
         return shadow, None
-    dy = K.scale_cast(dnew2, nrows, N, tc, row_idx=rows, gamma=gamma, alpha=alpha, drop_p=drop_p, seed=seed)
+    if gamma is None and rows is None and alpha == 1.0 and drop_p == 0.0 and dnew2.dtype == tc:
+        dy = dnew2   # nothing to scale, gather or cast (pure-bf16 parameters without layer scale or drop-path)
+    else:
+        dy = K.scale_cast(dnew2, nrows, N, tc, row_idx=rows, gamma=gamma, alpha=alpha, drop_p=drop_p, seed=seed)
     dgamma = None
     if gamma is not None and need_dgamma:
         dgamma = K.colsum(dnew2, nrows, N, N, gamma.dtype, a_idx=rows, b=aux, ldb=N, scale=alpha)

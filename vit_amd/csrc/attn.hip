@@ -515,7 +515,7 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
 }
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_fwd_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP p) {
 #ifdef EXP_STAMP   // diagnostic build: cycle stamps of wave 0 per block go to the lse buffer (tools/stamp_attn.py reads them)
   const uint64_t st0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -640,7 +640,7 @@ __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const ch
 }
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, (DHP <= 64 ? 2 : 1)) void attn_dq_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int KS = Strides<DHP>::COLS, VS = Strides<DHP>::ROWS;  // K is read both ways (swizzled), V row-wise only
   constexpr int TILE = 64 * KS + 64 * VS;

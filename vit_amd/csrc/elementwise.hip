@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
     const float rstd = rstd_in[r];
     const float mean = LN ? mean_in[r] : 0.f;
     float c1 = 0.f, c2 = 0.f;
+    float xhs[MAXIT][4], gs[MAXIT][4];   // normalised row and weighted gradient, kept for the second pass
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
       const int d = it * 256 + lane * 4;
@@ -121,6 +122,8 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
         for (int i = 0; i < 4; i++) {
           const float xh = (xv.v[i] - mean) * rstd;
           const float g = gv.v[i] * wv.v[i];
+          xhs[it][i] = xh;
+          gs[it][i] = g;
           c1 += g;
           c2 += g * xh;
           aw[it][i] += gv.v[i] * xh;
@@ -136,18 +139,11 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
     for (int it = 0; it < MAXIT; it++) {
       const int d = it * 256 + lane * 4;
       if (d < D) {
-        Vec4<TX> xv; xv.load(xr + d);
-        Vec4<TG> gv; gv.load(gr + d);
-        Vec4<TW> wv; wv.load(w + d);
         Vec4<TO> o;
         if (addr) o.load(addr + d);
         else { o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const float xh = (xv.v[i] - mean) * rstd;
-          const float g = gv.v[i] * wv.v[i];
-          o.v[i] += rstd * (g - c1 - xh * c2);
-        }
+        for (int i = 0; i < 4; i++) o.v[i] += rstd * (gs[it][i] - c1 - xhs[it][i] * c2);
         o.store(outr + d);
         if (shadow) {   // the next consumer multiplies this gradient in bf16: hand it the cast along with the fp32 rows
           Vec4<bf16> sv;

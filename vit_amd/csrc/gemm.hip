@@ -1204,10 +1204,25 @@ template <int MODE, class TI, class TO>
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ partial, int64_t M, int64_t N, int splits,
                                                        Epi e) {
   const int64_t total = M * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < splits; k++) s += partial[(int64_t)k * total + i];
-    EpiOp<MODE, TI, TO>::apply(e, i / N, i % N, s);
+  if (MODE == VITK_EPI_STORE && N % 4 == 0 && e.ldo % 4 == 0 && !e.bias) {   // 4 columns per thread, 16-byte accesses
+    const int64_t nq = N / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < M * nq; q += (int64_t)gridDim.x * 256) {
+      const int64_t m = q / nq, n = (q - m * nq) * 4;
+      float4 s = *(const float4*)(partial + m * N + n);
+      for (int k = 1; k < splits; k++) {
+        const float4 t = *(const float4*)(partial + (int64_t)k * total + m * N + n);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      Vec4<TO> o;
+      o.v[0] = s.x; o.v[1] = s.y; o.v[2] = s.z; o.v[3] = s.w;
+      o.store((TO*)e.out + m * e.ldo + n);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      float s = 0.f;
+      for (int k = 0; k < splits; k++) s += partial[(int64_t)k * total + i];
+      EpiOp<MODE, TI, TO>::apply(e, i / N, i % N, s);
+    }
   }
   if (e.asum) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {

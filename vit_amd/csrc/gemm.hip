@@ -124,9 +124,11 @@ struct EpiVec {
       o.store((TO*)e.out + m * e.ldo + n);
     } else if (MODE == VITK_EPI_RESIDUAL) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        v[j] = round_as<TI>(v[j]);
-        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
+      for (int j = 0; j < 4; j++) v[j] = round_as<TI>(v[j]);
+      if (e.thr) {   // one uniform branch for the vector, not one per element (a taken scalar branch costs a refetch)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
       }
       if (e.aux) {
         Vec4<TI> a;
@@ -504,7 +506,14 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, fl
     pl[j] = pa.get(j);
     pg[j] = pb.get(j);
     v[j] = round_as<TI>(v[j]);
-    if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+  }
+  if (e.thr) {   // one uniform branch for the vector, not one per element
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
     dl[j] = v[j];
     dg[j] = v[j];
   }

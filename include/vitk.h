@@ -189,6 +189,10 @@ int vitk_colsum(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, c
 int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, void* out,
                     int out_dtype, int64_t rows, int64_t N, float alpha, float drop_p, uint64_t seed, void* stream);
 
+/* Diagnostics (no counterpart in the reference): `blocks` idle workgroups that hold their CUs for about `cycles` shader
+ * clocks, to measure what a launch loses when another stream's kernel occupies part of the chip. */
+int vitk_debug_hold_cus(int blocks, long long cycles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -807,3 +807,26 @@ extern "C" int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const in
   VITK_LAUNCH_CHECK("scale_cast");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Diagnostics: `blocks` workgroups of one wave per SIMD that stay resident for about `cycles` shader clocks and do
+// nothing -- a stand-in for a collective's kernel on a side stream, to see what a launch on the main stream loses when
+// some CUs are taken (tools/bench_hog.py).  The loop is bounded by the clock AND by an iteration count.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void debug_hold_cus_k(long long cycles, unsigned int* sink) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  unsigned int n = 0;
+  for (long long it = 0; it < (1ll << 26); it++) {
+    if ((long long)__builtin_amdgcn_s_memtime() - t0 >= cycles) break;
+    __builtin_amdgcn_s_sleep(32);
+    n++;
+  }
+  if (sink && n == 0xffffffffu) *sink = n;
+}
+
+extern "C" int vitk_debug_hold_cus(int blocks, long long cycles, void* stream) {
+  VITK_REQUIRE(blocks > 0 && blocks <= 1024 && cycles > 0 && cycles <= (1ll << 34), "debug_hold_cus: bad arguments");
+  hipLaunchKernelGGL(debug_hold_cus_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, cycles, (unsigned int*)nullptr);
+  VITK_LAUNCH_CHECK("debug_hold_cus");
+  return 0;
+}

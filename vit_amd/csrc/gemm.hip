@@ -10,6 +10,7 @@
 // Both share the epilogue functors (bias / residual + layer-scale + dropout + drop-path scatter /
 // patch-embedding placement + position add).
 #include "common.h"
+#include <atomic>
 
 struct Epi {
   void* out;
@@ -1081,10 +1082,17 @@ __device__ __forceinline__ void slab_stage16(float* stg, const f32x4_t (&acc)[8]
         stg[(16 * h + 4 * (lane >> 4) + r) * STG_LD + 16 * j + (lane & 15)] = acc[2 * s + h][j][r];
 }
 
+// Tile counters of the DMA kernel: per launch slot 8 per-XCD draw counters and, at [8], the number of blocks that have
+// left.  Zero at load; every launch leaves its slot zero again.  Launches that may overlap (different streams) get
+// different slots from the host's round-robin.
+constexpr int TILE_CTR_SLOTS = 64;
+__device__ unsigned int g_tile_ctr[TILE_CTR_SLOTS][16];
+
 template <bool TA, bool TB, int MODE, class TO>
 __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ A, const bf16* __restrict__ B, int64_t M,
                                                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
-                                                       int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial) {
+                                                       int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial,
+                                                       int slot) {
   __shared__ __attribute__((aligned(1024))) char smem[4 * SLOT_B];
 #ifdef EXP_STAMP
   const uint64_t st0 = __builtin_amdgcn_s_memtime();
@@ -1092,10 +1100,22 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;
   const int wm = grp, wn = wid & 3;
-  // A block walks tiles blockIdx.x, + gridDim.x, ... (the host launches one block per CU): a block launch costs a few
-  // microseconds, which is noticeable beside a short-K tile.
+  // The host launches one block per CU and every block walks several tiles (a block launch costs a few microseconds,
+  // noticeable beside a short-K tile).  Which tiles is decided as the kernel runs: the blocks of an XCD (blockIdx & 7)
+  // share that XCD's run of consecutive tile ids and draw the next one from a counter, so a CU that is slow, or not
+  // available at all because another kernel (a collective on a side stream) holds it, takes fewer tiles instead of
+  // making the whole launch wait for its fixed share.  The draw for the next tile is issued before the current one
+  // starts and consumed after its epilogue.
   const int64_t total_tiles = tiles_m * tiles_n * ((K + klen - 1) / klen);
-  for (int64_t vt = blockIdx.x; vt < total_tiles; vt += gridDim.x) {
+  const int xcd = blockIdx.x & 7;
+  const int64_t xcd_tiles = (total_tiles >> 3) + (xcd < (total_tiles & 7) ? 1 : 0);
+  const int64_t xcd_blocks = ((int64_t)gridDim.x - xcd + 7) >> 3;
+  unsigned int* ctr = g_tile_ctr[slot];
+  __shared__ unsigned int s_next;
+  for (int64_t jt = blockIdx.x >> 3; jt < xcd_tiles;) {
+  const int64_t vt = xcd + 8 * jt;
+  unsigned int drawn = 0;
+  if (tid == 0) drawn = __hip_atomic_fetch_add(&ctr[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int64_t wg = xcd_remap(vt, total_tiles);
   int64_t tm, tn, split;
   tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
@@ -1193,7 +1213,17 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
     slab_stage16(stg, acc, sl, lane);
     slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
   }
+  if (tid == 0) s_next = drawn;
   __syncthreads();   // the staging slabs overlay the ring: done before the next tile's first requests
+  jt = xcd_blocks + s_next;
+  }
+  // the last block to leave re-arms the counters for the next launch that uses this slot
+  if (tid == 0) {
+    const unsigned int left = __hip_atomic_fetch_add(&ctr[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) __hip_atomic_store(&ctr[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #ifdef EXP_STAMP   // diagnostic build: per-block cycle stamps overwrite the start of aux (tools/stamp_gemm.py reads them)
   const uint64_t st3 = __builtin_amdgcn_s_memtime();
@@ -1351,15 +1381,32 @@ static int64_t cu_count() {
   return cached;
 }
 
+// blocks of a DMA-kernel launch: the CU count, or VITK_GEMM_BLOCKS (experiments)
+static int64_t gemm_blocks() {
+  static const int64_t n = [] {
+    const char* f = getenv("VITK_GEMM_BLOCKS");
+    const int64_t v = f ? atoll(f) : 0;
+    return v > 0 && v <= cu_count() ? v : (int64_t)cu_count();
+  }();
+  return n;
+}
+
+static int next_tile_slot() {
+  static std::atomic<unsigned> launches{0};
+  return (int)(launches.fetch_add(1) % TILE_CTR_SLOTS);
+}
+
 template <bool TA, bool TB, int MODE, class TO>
 static void launch_mfma_one(const VitkGemm* g, const Epi& e, int splits, int64_t klen, float* partial, hipStream_t st) {
   if (use_tile256(g)) {
     const int64_t tm = ceil_div(g->M, BM2), tn = ceil_div(g->N, BN2);
     if (g->algo != 3) {   // algo 3 keeps the register-staged 32x32x16 kernel for comparisons
       int64_t nblk = tm * tn * splits;
-      if (nblk > cu_count()) nblk = cu_count();   // one resident block per CU (LDS); each walks several tiles
+      if (nblk > gemm_blocks()) nblk = gemm_blocks();   // at most one resident block per CU (LDS); each walks several tiles
+      const int slot = next_tile_slot();
       hipLaunchKernelGGL((gemm_mfma256d_k<TA, TB, MODE, TO>), dim3((unsigned)nblk), dim3(512), 0, st,
-                         (const bf16*)g->a, (const bf16*)g->b, g->M, g->N, g->K, g->lda, g->ldb, tm, tn, klen, e, partial);
+                         (const bf16*)g->a, (const bf16*)g->b, g->M, g->N, g->K, g->lda, g->ldb, tm, tn, klen, e, partial,
+                         slot);
       return;
     }
     hipLaunchKernelGGL((gemm_mfma256_k<TA, TB, MODE, TO>), dim3((unsigned)(tm * tn * splits)), dim3(512), 0, st,

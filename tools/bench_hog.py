@@ -26,6 +26,6 @@ def timed(hog_blocks):
     return e0.elapsed_time(e1) / 10
 base = timed(0)
 print(f"fc1 forward GEMM alone: {base:.3f} ms")
-for hb in (16, 32, 64):
+for hb in (16, 32, 64, 128, 192):
     t = timed(hb)
     print(f"  with {hb:3d} CUs held: {t:.3f} ms  ({t / base:.2f}x; ideal {256 / (256 - hb):.2f}x)")

@@ -826,7 +826,9 @@ __global__ __launch_bounds__(256) void debug_hold_cus_k(long long cycles, unsign
 
 extern "C" int vitk_debug_hold_cus(int blocks, long long cycles, void* stream) {
   VITK_REQUIRE(blocks > 0 && blocks <= 1024 && cycles > 0 && cycles <= (1ll << 34), "debug_hold_cus: bad arguments");
-  hipLaunchKernelGGL(debug_hold_cus_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, cycles, (unsigned int*)nullptr);
+  // 96 KiB of (unused) LDS per workgroup: no two of them fit one CU, so `blocks` CUs are held
+  hipLaunchKernelGGL(debug_hold_cus_k, dim3((unsigned)blocks), dim3(256), 96 * 1024, (hipStream_t)stream, cycles,
+                     (unsigned int*)nullptr);
   VITK_LAUNCH_CHECK("debug_hold_cus");
   return 0;
 }

@@ -189,6 +189,11 @@ int vitk_colsum(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, c
 int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, void* out,
                     int out_dtype, int64_t rows, int64_t N, float alpha, float drop_p, uint64_t seed, void* stream);
 
+/* Library options (no counterpart in the reference).  "dynamic_tiles" = 1: the blocks of the large-tile GEMM kernel
+ * draw their tiles from counters instead of taking fixed shares; for processes whose collectives run on a side stream
+ * beside the GEMMs and hold CUs meanwhile (vit_amd/ddp.py sets it when the process group has more than one rank). */
+int vitk_set_option(const char* name, int value);
+
 /* Diagnostics (no counterpart in the reference): `blocks` idle workgroups that hold their CUs for about `cycles` shader
  * clocks, to measure what a launch loses when another stream's kernel occupies part of the chip. */
 int vitk_debug_hold_cus(int blocks, long long cycles, void* stream);

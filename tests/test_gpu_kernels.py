@@ -436,3 +436,35 @@ def test_standalone_apply_rope_matches_reference_vectors(tag):
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-5, atol=1e-6)
     per = torch.stack([t32, t32.flip(1)], 1)[:, :, None]   # [2, B=2, 1, N, Dh]
     torch.testing.assert_close(apply_rope(q.float(), per), O.apply_rope(q.float(), per), rtol=1e-5, atol=1e-6)
+
+
+def test_gemm_dynamic_tile_shares_match_fixed_ones():
+    """vitk_set_option("dynamic_tiles", 1): the blocks of the 256x256-tile kernel draw tiles from per-XCD counters.  Same
+    exact products as with fixed shares, on launches with fewer, as many and more tiles than CUs, several launches in a
+    row (each re-arms its counter slot), with split-K and with idle workgroups on a side stream holding CUs meanwhile."""
+    from vit_amd import _lib as L
+
+    lib = L.load()
+    g = torch.Generator().manual_seed(0)
+    cases = [(512, 512, 256, "nt"), (4096, 4096, 128, "nn"), (8192, 4608, 192, "nt"), (768, 768, 16384, "tn")]
+    try:
+        L.check(lib.vitk_set_option(b"dynamic_tiles", 1))
+        side = torch.cuda.Stream()
+        for rep in range(3):
+            if rep == 2:
+                with torch.cuda.stream(side):
+                    L.check(lib.vitk_debug_hold_cus(48, 20_000_000, side.cuda_stream))
+            for M, N, Kd, layout in cases:
+                A = torch.randint(-2, 3, (M, Kd), generator=g).float()
+                B = torch.randint(-2, 3, (Kd, N), generator=g).float()
+                ref = (A @ B).to(DEV)
+                a = (A if layout != "tn" else A.t()).contiguous().to(DEV, torch.bfloat16)
+                b = (B.t() if layout == "nt" else B).contiguous().to(DEV, torch.bfloat16)
+                out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+                K.gemm(a, b, trans_a=layout == "tn", trans_b=layout != "nt", M=M, N=N, K=Kd, out=out, algo=5)
+                assert torch.equal(out, ref), f"rep {rep} {M}x{N}x{Kd} {layout}: max err {(out - ref).abs().max().item()}"
+        torch.cuda.synchronize()
+    finally:
+        L.check(lib.vitk_set_option(b"dynamic_tiles", 0))
+    with pytest.raises(RuntimeError, match="unknown option"):
+        L.check(lib.vitk_set_option(b"no_such_option", 1))

@@ -17,7 +17,7 @@ ACT_CODES = {"relu": 0, "reglu": 0, "silu": 1, "swiglu": 1, "gelu": 2, "geglu": 
 
 EXPORTS = [
     "vitk_version", "vitk_last_error", "vitk_norm_fwd", "vitk_norm_bwd", "vitk_norm_bwd_workspace_bytes",
-    "vitk_gemm", "vitk_gemm_workspace_bytes", "vitk_attn_fwd", "vitk_attn_bwd", "vitk_attn_weights", "vitk_rope_qk", "vitk_rope_rows", "vitk_debug_hold_cus", "vitk_act_fwd",
+    "vitk_gemm", "vitk_gemm_workspace_bytes", "vitk_attn_fwd", "vitk_attn_bwd", "vitk_attn_weights", "vitk_rope_qk", "vitk_rope_rows", "vitk_debug_hold_cus", "vitk_set_option", "vitk_act_fwd",
     "vitk_act_bwd", "vitk_im2col", "vitk_col2im", "vitk_colsum", "vitk_colsum_workspace_bytes", "vitk_scale_cast",
 ]
 
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
         "vitk_attn_bwd": [C.POINTER(VitkAttn), vp],
         "vitk_attn_weights": [C.POINTER(VitkAttn), vp, vp],
         "vitk_debug_hold_cus": [i32, C.c_longlong, vp],
+        "vitk_set_option": [C.c_char_p, i32],
         "vitk_rope_qk": [vp, i32, vp, i64, i64, i64, i64, i64, i32, i32, i32, vp],
         "vitk_rope_rows": [vp, i32, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
         "vitk_act_fwd": [vp, vp, i32, i64, i64, i32, i32, i32, f32, i32, f32, f32, u64, vp],

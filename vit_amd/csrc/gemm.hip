@@ -11,6 +11,7 @@
 // patch-embedding placement + position add).
 #include "common.h"
 #include <atomic>
+#include <string.h>
 
 struct Epi {
   void* out;
@@ -1110,12 +1111,13 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   const int xcd = blockIdx.x & 7;
   const int64_t xcd_tiles = (total_tiles >> 3) + (xcd < (total_tiles & 7) ? 1 : 0);
   const int64_t xcd_blocks = ((int64_t)gridDim.x - xcd + 7) >> 3;
-  unsigned int* ctr = g_tile_ctr[slot];
+  const bool dynamic = slot >= 0;   // slot < 0: fixed shares, block b of an XCD takes that XCD's tiles b, b + blocks, ...
+  unsigned int* ctr = g_tile_ctr[dynamic ? slot : 0];
   __shared__ unsigned int s_next;
   for (int64_t jt = blockIdx.x >> 3; jt < xcd_tiles;) {
   const int64_t vt = xcd + 8 * jt;
   unsigned int drawn = 0;
-  if (tid == 0) drawn = __hip_atomic_fetch_add(&ctr[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (dynamic && tid == 0) drawn = __hip_atomic_fetch_add(&ctr[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int64_t wg = xcd_remap(vt, total_tiles);
   int64_t tm, tn, split;
   tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
@@ -1213,12 +1215,12 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
     slab_stage16(stg, acc, sl, lane);
     slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
   }
-  if (tid == 0) s_next = drawn;
+  if (dynamic && tid == 0) s_next = drawn;
   __syncthreads();   // the staging slabs overlay the ring: done before the next tile's first requests
-  jt = xcd_blocks + s_next;
+  jt = dynamic ? xcd_blocks + s_next : jt + xcd_blocks;
   }
   // the last block to leave re-arms the counters for the next launch that uses this slot
-  if (tid == 0) {
+  if (dynamic && tid == 0) {
     const unsigned int left = __hip_atomic_fetch_add(&ctr[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (left == gridDim.x - 1) {
 #pragma unroll
@@ -1391,7 +1393,19 @@ static int64_t gemm_blocks() {
   return n;
 }
 
+// Tile shares of the DMA kernel: fixed by default (a little faster when nothing else runs on the GPU), drawn from the
+// counters when the caller expects another stream's kernels to hold CUs during the launches (data-parallel training:
+// the gradient all-reduce runs beside the backward pass).
+static std::atomic<int> g_dynamic_tiles{0};
+
+extern "C" int vitk_set_option(const char* name, int value) {
+  VITK_REQUIRE(name != nullptr, "set_option: null name");
+  if (strcmp(name, "dynamic_tiles") == 0) { g_dynamic_tiles.store(value != 0); return 0; }
+  return vitk_set_error("set_option: unknown option '%s'", name);
+}
+
 static int next_tile_slot() {
+  if (!g_dynamic_tiles.load()) return -1;
   static std::atomic<unsigned> launches{0};
   return (int)(launches.fetch_add(1) % TILE_CTR_SLOTS);
 }

@@ -62,6 +62,11 @@ class BucketedGradAllReduce:
                 self._where[p] = (b, i)
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        if self.world > 1 and backend == "nccl":
+            # the all-reduce kernels will hold CUs beside the backward GEMMs: let those draw their tiles dynamically
+            from . import _lib as L
+
+            L.check(L.load().vitk_set_option(b"dynamic_tiles", 1))
         self._avg = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
         self._div = backend != "nccl"
 

@@ -228,6 +228,23 @@ def test_attention_forward_backward(S, Dh, mode):
         close(dqkv[:, i * D:(i + 1) * D], dqkv_ref[:, i * D:(i + 1) * D], tol, msg="d" + name)
 
 
+def test_attention_long_sequence_head_dim_88():
+    """The long-sequence shape of ViT-g/14 at 1024 px: S = 5329 (84 key tiles, ragged last tile), head_dim 88 (the 96-wide
+    kernel instances, 4 waves per block for S >= 2048), forward and both backward kernels against fp64 math."""
+    B, H, S, Dh = 1, 2, 5329, 88
+    g = torch.Generator().manual_seed(5329)
+    qkv = torch.randn(B * S, 3 * H * Dh, generator=g).to(DEV, torch.bfloat16)
+    dout = torch.randn(B * S, H * Dh, generator=g).to(DEV, torch.bfloat16)
+    o, lse = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, algo=2)
+    dqkv = K.attn_bwd(qkv, o, lse, dout, B, S, H, Dh, Dh ** -0.5, algo=2)
+    o_ref, lse_ref, dqkv_ref = attn_reference(qkv, B, S, H, Dh, dout)
+    close(o, o_ref, 2e-2, msg="o")
+    close(lse, lse_ref, 1e-3, msg="lse")
+    D = H * Dh
+    for i, name in enumerate("qkv"):
+        close(dqkv[:, i * D:(i + 1) * D], dqkv_ref[:, i * D:(i + 1) * D], 2e-2, msg="d" + name)
+
+
 def test_attention_online_softmax_rescale_spike():
     """Force the running max to jump at a late key tile (a rare data-dependent branch of online softmax)."""
     B, H, S, Dh = 1, 1, 256, 64

@@ -426,6 +426,16 @@ def test_vit_h14_droppath_layerscale_ckpt_bf16_runs_and_matches_oracle():
     compare_with_oracle_on_gpu(cfg, 4, (224, 224), False, 3e-2, grad_rtol=8e-2, oracle_device="cuda")
 
 
+def test_vit_g14_1024px_long_sequence_bf16_matches_oracle():
+    """BASELINE config 5 at depth 1, batch 1: ViT-g/14 at 1024 px, S = 73 * 73 = 5329 tokens (the last 2 pixels of each axis
+    fall off the patch grid), D = 1408, head_dim 88, F = 6144, SwiGLU + RoPE, pure bf16 parameters."""
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(1024, 1024), depth=1, hidden_size=1408,
+                    ffn_hidden_size=6144, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
+                    activation="swiglu", pos_enc="rope", dtype=torch.bfloat16)
+    model = compare_with_oracle_on_gpu(cfg, 1, (1024, 1024), False, 2e-2, grad_rtol=5e-2)
+    assert model.stem.tokenized_size((1024, 1024)) == (73, 73)
+
+
 def test_vit_s16_fp32_forward_config1():
     """BASELINE config 1 (ViT-S/16 224 fp32 forward, batch 8) on the GPU kernels vs the oracle."""
     cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(224, 224), depth=12, hidden_size=384,

@@ -183,6 +183,15 @@ size_t vitk_colsum_workspace_bytes(int64_t N);
 int vitk_colsum(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, const void* b, int b_dtype, int64_t ldb,
                 void* out, int out_dtype, int64_t rows, int64_t N, float scale, void* workspace, void* stream);
 
+/* vitk_colsum without a workspace argument and without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate device memory around the call (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  The per-chunk partial sums go to a device array built into the library (8 MiB per
+ * GPU, held until the process ends), so N is limited to 8192 columns; larger N is rejected with an error.  All calls on
+ * one GPU share that array: calls that overlap on one GPU (different streams) race -- serialise them.  The first call on
+ * a device looks up the array's address (no allocation); make that call outside graph capture. */
+int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, const void* b, int b_dtype, int64_t ldb,
+                       void* out, int out_dtype, int64_t rows, int64_t N, float scale, void* stream);
+
 /* ---- gradient preparation for the residual branch: backward of merge + layer scale + dropout -------
  * (vit/transformer.py:30-38, vit/layer_scale.py:8-13, F.dropout):
  * out[r, n] = dropmask(r, n) * alpha * gamma[n] * g[row(r), n], cast to out_dtype. */

@@ -2,6 +2,7 @@
 // MLP activations (plain and GLU), RoPE on the packed projection, patch unfolding, gradient preparation.
 // All of them stream rows with 4-wide vector accesses (16 B fp32 / 8 B bf16 per lane), fp32 math.
 #include "common.h"
+#include <mutex>
 #include <string>
 
 // ------------------------------------------------------------------------------------------------
@@ -295,6 +296,41 @@ extern "C" int vitk_colsum(const void* a, int a_dtype, int64_t lda, const int64_
                    { return colsum_launch<TA, TB>(a, lda, a_idx, b, ldb, out, out_dtype, rows, N, scale, workspace, st); });
   });
   return 0;
+}
+
+// vitk_colsum for callers that may not allocate: the per-chunk partial sums live in a file-scope device array
+// instead of a caller workspace.  Every GPU holds its own copy of the array at its own address; the address is
+// looked up once per device (with that device current) and only that pointer is ever handed to kernels.
+constexpr int64_t COLSUM_STATIC_MAX_N = 8192;   // 256 chunks x 8192 columns x 4 B = 8 MiB per GPU
+static __device__ __align__(256) float scratch[COLSUM_CHUNKS * COLSUM_STATIC_MAX_N];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static float* g_scratch_ptr[SCRATCH_MAX_DEVICES];   // per device: device address of `scratch`, or null before set-up
+
+static int scratch_for_current_device(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCRATCH_MAX_DEVICES)
+    return vitk_set_error("colsum_static: cannot identify the current device (index %d)", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    float* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) return vitk_set_error("colsum_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+
+extern "C" int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, const void* b, int b_dtype,
+                                  int64_t ldb, void* out, int out_dtype, int64_t rows, int64_t N, float scale, void* stream) {
+  VITK_REQUIRE(a && out && rows >= 0 && N > 0, "colsum_static: bad arguments");
+  VITK_REQUIRE(N <= COLSUM_STATIC_MAX_N, "colsum_static: N=%lld exceeds the built-in scratch (at most %lld columns); use vitk_colsum "
+               "with a caller workspace", (long long)N, (long long)COLSUM_STATIC_MAX_N);
+  float* ws = nullptr;
+  if (int rc = scratch_for_current_device(&ws)) return rc;
+  // every chunk row that the second pass reads is written whole by the first pass: nothing has to start at zero
+  return vitk_colsum(a, a_dtype, lda, a_idx, b, b_dtype, ldb, out, out_dtype, rows, N, scale, ws, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,9 +36,43 @@ def _worker(rank: int, world: int, port: int, q):
                 assert torch.allclose(p.grad, torch.full_like(p, expect)), (step, i, p.grad[:3], expect)
             assert torch.all(unused.grad == 0)
             assert frozen.grad is None
+        # rank-dependent unused parameters: rank 0 never touches params[1], rank 1 never touches params[3]; the buckets
+        # must still be issued in the same order on both ranks (a mismatch pairs buckets of different sizes: hang/corrupt)
+        for p in params + [unused]:
+            p.grad = None
+        skip = 1 if rank == 0 else 3
+        loss = sum((rank + 1) * (i + 1) * p.sum() for i, p in enumerate(params) if i != skip)
+        loss.backward()
+        red.finish()
+        for i, p in enumerate(params):
+            expect = sum((r + 1) * (i + 1) for r in range(world) if i != (1 if r == 0 else 3)) / world
+            assert torch.allclose(p.grad, torch.full_like(p, expect)), ("unused", i, p.grad[:3], expect)
+        # a second backward before finish() must raise instead of accumulating into a buffer that is being reduced
+        for p in params + [unused]:
+            p.grad = None
+        sum(p.sum() for p in params).backward()
+        try:
+            sum(p.sum() for p in params).backward()
+            raise AssertionError("second backward before finish() did not raise")
+        except RuntimeError as e:
+            assert "no_sync" in str(e)
+        red.finish()
+        # gradient accumulation: first micro-batch under no_sync(), second synchronised
+        for p in params + [unused]:
+            p.grad = None
+        with red.no_sync():
+            sum((rank + 1) * p.sum() for p in params).backward()
+        sum(2.0 * p.sum() for p in params).backward()
+        red.finish()
+        for i, p in enumerate(params):
+            expect = sum((r + 1) + 2.0 for r in range(world)) / world
+            assert torch.allclose(p.grad, torch.full_like(p, expect)), ("accum", i, p.grad[:3], expect)
+        red.remove()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
-        q.put((rank, repr(e)))
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
     finally:
         dist.destroy_process_group()
 

@@ -8,17 +8,42 @@ local batch), so the only exchange per step is the gradient average.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU); a ring all-reduce is bound by one link, so buckets are sized
 large enough (default 64 MiB) to be bandwidth- rather than latency-bound while still leaving several buckets per
-step to overlap with compute."""
+step to overlap with compute.
+
+Weight gradients can be produced straight into the bucket: while a reducer is attached, ``grad_sink(param)`` hands
+the backward kernels the bucket's slice for that parameter, autograd adopts it as ``param.grad`` without a copy, and
+the hook finds the gradient already in place."""
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+import contextlib
+from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
+# parameter storage address -> (reducer, bucket, index); consulted by the backward kernels' host code (vit_amd/ops.py)
+_SINKS: Dict[int, tuple] = {}
+
+
+def grad_sink(param_ptr: int, shape, dtype: torch.dtype) -> Optional[torch.Tensor]:
+    """The bucket slice that the gradient of the parameter stored at ``param_ptr`` is reduced from, if a reducer is
+    attached to it, the slice has not been handed out yet in this step and gradients are being synchronised; else None
+    (the caller allocates)."""
+    entry = _SINKS.get(param_ptr)
+    if entry is None:
+        return None
+    red, b, i = entry
+    if not red._sync or b.issued or b.given[i]:
+        return None
+    p = b.params[i]
+    if tuple(p.shape) != tuple(shape) or p.dtype != dtype:
+        return None
+    b.given[i] = True
+    return red._view(b, i)
+
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "work")
+    __slots__ = ("params", "offsets", "flat", "arrived", "given", "work", "issued")
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
@@ -26,18 +51,26 @@ class _Bucket:
         for p in params:
             self.offsets.append(n)
             n += (p.numel() + 63) // 64 * 64  # keep every slice 256-byte aligned
-        self.flat = torch.empty(n, dtype=params[0].dtype, device=params[0].device)
-        self.pending = len(params)
+        self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.arrived = [False] * len(params)
+        self.given = [False] * len(params)
         self.work = None
+        self.issued = False
 
 
 class BucketedGradAllReduce:
     """Averages ``p.grad`` of every trainable parameter over the process group, bucket by bucket.
 
-    Buckets are filled in reverse registration order (the order gradients become ready in backward).  When the last
-    gradient of a bucket has been accumulated the bucket's flat buffer is all-reduced asynchronously; ``finish()``
-    waits for all buckets and leaves ``p.grad`` pointing at the averaged values (views into the flat buffers).
-    Parameters that did not receive a gradient in a step are reduced as zeros in ``finish()``."""
+    Buckets are filled in reverse registration order (the order gradients become ready in backward).  A bucket is
+    all-reduced asynchronously once all its gradients have arrived AND every earlier bucket has been issued, so every
+    rank issues the collectives in the same order (bucket 0, 1, 2, ...) whatever order its gradients arrive in;
+    ``finish()`` issues what is left (parameters without a gradient contribute zeros), waits for all buckets and
+    leaves ``p.grad`` pointing at the averaged values (views into the flat buffers).
+
+    One backward pass per ``finish()``: a second gradient for a parameter before ``finish()`` raises, because it would
+    be accumulated in place into a buffer whose all-reduce may be in flight.  For gradient accumulation run the
+    earlier micro-batches under ``no_sync()`` (hooks do nothing, gradients accumulate in ``p.grad`` as usual) and the
+    last one outside it."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group: Optional[dist.ProcessGroup] = None,
                  bucket_bytes: int = 64 << 20):
@@ -57,16 +90,20 @@ class BucketedGradAllReduce:
             self.buckets.append(_Bucket(cur))
         self._where = {}
         self._handles = []
+        self._sync = True
+        self._next = 0   # index of the first bucket not yet issued
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                _SINKS[p.data_ptr()] = (self, b, i)
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
-        if self.world > 1 and backend == "nccl":
-            # the all-reduce kernels will hold CUs beside the backward GEMMs: let those draw their tiles dynamically
-            from . import _lib as L
+        # the all-reduce kernels hold CUs beside the backward GEMMs: those then draw their tiles dynamically
+        self.dynamic_tiles = self.world > 1 and backend == "nccl"
+        if self.dynamic_tiles:
+            from . import kernels as K
 
-            L.check(L.load().vitk_set_option(b"dynamic_tiles", 1))
+            self._old_dynamic = K.set_dynamic_tiles(True)
         self._avg = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
         self._div = backend != "nccl"
 
@@ -74,42 +111,76 @@ class BucketedGradAllReduce:
         p = b.params[i]
         return b.flat[b.offsets[i]: b.offsets[i] + p.numel()].view_as(p)
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context leave ``p.grad`` alone (no copy, no all-reduce)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
     def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self._sync:
+            return
         b, i = self._where[p]
+        if b.issued or b.arrived[i]:
+            raise RuntimeError("BucketedGradAllReduce: a parameter received a second gradient before finish(); run "
+                               "accumulation micro-batches under no_sync() and call finish() after every synchronised "
+                               "backward pass")
         v = self._view(b, i)
         if p.grad.data_ptr() != v.data_ptr():
             v.copy_(p.grad)
             p.grad = v
-        b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        b.arrived[i] = True
+        self._issue_ready()
+
+    def _issue_ready(self) -> None:
+        while self._next < len(self.buckets) and all(self.buckets[self._next].arrived):
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b: _Bucket) -> None:
+        b.issued = True
         if self.world > 1:
             b.work = dist.all_reduce(b.flat, op=self._avg, group=self.group, async_op=True)
 
     def finish(self) -> None:
-        """Call after backward: reduce stragglers, wait for every bucket, re-arm for the next step."""
-        for b in self.buckets:
-            if b.pending > 0:  # some parameter got no gradient this step: contribute zeros
-                for i, p in enumerate(b.params):
-                    if p.grad is None or p.grad.data_ptr() != self._view(b, i).data_ptr():
-                        v = self._view(b, i)
-                        if p.grad is None:
-                            v.zero_()
-                        else:
-                            v.copy_(p.grad)
-                        p.grad = v
-                self._launch(b)
+        """Call after backward: issue the remaining buckets in order, wait for every bucket, re-arm for the next step."""
+        for b in self.buckets[self._next:]:
+            for i, p in enumerate(b.params):
+                if b.arrived[i]:
+                    continue
+                v = self._view(b, i)
+                if p.grad is None:
+                    v.zero_()    # no gradient this step: contribute zeros
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                p.grad = v
+                b.arrived[i] = True
+            self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
                 if self._div:
                     b.flat.div_(self.world)
-            b.pending = len(b.params)
+            b.arrived = [False] * len(b.params)
+            b.given = [False] * len(b.params)
+            b.issued = False
+        self._next = 0
 
     def remove(self) -> None:
         for h in self._handles:
             h.remove()
         self._handles = []
+        for b in self.buckets:
+            for p in b.params:
+                if _SINKS.get(p.data_ptr(), (None,))[0] is self:
+                    del _SINKS[p.data_ptr()]
+        if self.dynamic_tiles:
+            from . import kernels as K
+
+            K.set_dynamic_tiles(self._old_dynamic)
+            self.dynamic_tiles = False

@@ -22,6 +22,18 @@ def set_algo(algo: int) -> int:
     return old
 
 
+_DYNAMIC_TILES = False  # large-tile GEMM blocks draw tiles from counters (set by the data-parallel reducer)
+
+
+def set_dynamic_tiles(on: bool) -> bool:
+    """Ask the large-tile GEMM launches of this process to hand out tiles dynamically: for processes whose collectives
+    run on a side stream beside the GEMMs and hold CUs meanwhile.  Returns the previous setting."""
+    global _DYNAMIC_TILES
+    old, _DYNAMIC_TILES = _DYNAMIC_TILES, bool(on)
+    L.check(L.load().vitk_set_option(b"dynamic_tiles", int(_DYNAMIC_TILES)))
+    return old
+
+
 def _c(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 

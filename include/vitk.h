@@ -13,8 +13,10 @@
  *   - return value 0 = launched; non-zero = rejected, with the reason in vitk_last_error()
  *     (thread-local, valid until the next failing call on the same thread);
  *   - dtype codes: VITK_F32 = 0, VITK_BF16 = 1;
- *   - functions are re-entrant and keep no mutable global state (forward runs on the caller's
- *     thread, backward on the autograd engine's thread).
+ *   - functions are re-entrant (forward runs on the caller's thread, backward on the autograd engine's
+ *     thread).  State kept between calls: the thread-local error string, the CU count of the first device
+ *     used, and (vitk_colsum_static only) the per-device address of its built-in scratch array.  Nothing
+ *     else: options travel in the argument structs.
  */
 #ifndef VITK_H
 #define VITK_H
@@ -106,6 +108,10 @@ typedef struct VitkGemm {
   float extra_bias;
   void* a_colsum;        /* STORE with trans_a = 1 only, or NULL: a_colsum[m] = sum_k A[k,m], dtype out_dtype -- the bias
                             gradient (autograd's dy.sum(0)) that accompanies a weight gradient dW = dy^T x, from the same pass */
+  int32_t dynamic_tiles; /* 1: the workgroups of the large-tile kernels draw their tiles from counters (kept in the last
+                            256 bytes of the workspace and zeroed on `stream` by the call) instead of taking fixed shares;
+                            for callers whose collectives run on another stream beside the GEMMs and hold CUs meanwhile
+                            (vit_amd/ddp.py).  vitk_gemm_workspace_bytes accounts for the counters. */
 } VitkGemm;
 
 size_t vitk_gemm_workspace_bytes(const VitkGemm* g);
@@ -197,11 +203,6 @@ int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const int64_t* a
  * out[r, n] = dropmask(r, n) * alpha * gamma[n] * g[row(r), n], cast to out_dtype. */
 int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, void* out,
                     int out_dtype, int64_t rows, int64_t N, float alpha, float drop_p, uint64_t seed, void* stream);
-
-/* Library options (no counterpart in the reference).  "dynamic_tiles" = 1: the blocks of the large-tile GEMM kernel
- * draw their tiles from counters instead of taking fixed shares; for processes whose collectives run on a side stream
- * beside the GEMMs and hold CUs meanwhile (vit_amd/ddp.py sets it when the process group has more than one rank). */
-int vitk_set_option(const char* name, int value);
 
 /* Diagnostics (no counterpart in the reference): `blocks` idle workgroups that hold their CUs for about `cycles` shader
  * clocks, to measure what a launch loses when another stream's kernel occupies part of the chip. */

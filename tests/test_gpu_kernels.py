@@ -30,7 +30,7 @@ def test_library_loads_and_reports_errors():
 
 # ---------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 72), (384, 264, 200), (1000, 72, 328), (768, 512, 448)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 72), (384, 264, 200), (1000, 72, 328), (768, 512, 448), (520, 392, 1280)])
 def test_mfma_gemm_exact_on_integers(layout, shape):
     """A = small integers, B = asymmetric small integers: every product and sum is exact in bf16/fp32, so the
     MFMA kernel (operand lane maps, transposed LDS reads, C layout, tails) must match torch bit for bit."""
@@ -456,16 +456,17 @@ def test_standalone_apply_rope_matches_reference_vectors(tag):
 
 
 def test_gemm_dynamic_tile_shares_match_fixed_ones():
-    """vitk_set_option("dynamic_tiles", 1): the blocks of the 256x256-tile kernel draw tiles from per-XCD counters.  Same
-    exact products as with fixed shares, on launches with fewer, as many and more tiles than CUs, several launches in a
-    row (each re-arms its counter slot), with split-K and with idle workgroups on a side stream holding CUs meanwhile."""
+    """VitkGemm.dynamic_tiles = 1: the blocks of the 256x256-tile kernels draw tiles from per-XCD counters kept in the
+    workspace.  Same exact products as with fixed shares, on launches with fewer, as many and more tiles than CUs, several
+    launches in a row (each call zeroes its counters), with split-K, and with idle workgroups on a side stream holding
+    CUs meanwhile."""
     from vit_amd import _lib as L
 
     lib = L.load()
     g = torch.Generator().manual_seed(0)
     cases = [(512, 512, 256, "nt"), (4096, 4096, 128, "nn"), (8192, 4608, 192, "nt"), (768, 768, 16384, "tn")]
+    old = K.set_dynamic_tiles(True)
     try:
-        L.check(lib.vitk_set_option(b"dynamic_tiles", 1))
         side = torch.cuda.Stream()
         for rep in range(3):
             if rep == 2:
@@ -482,6 +483,4 @@ def test_gemm_dynamic_tile_shares_match_fixed_ones():
                 assert torch.equal(out, ref), f"rep {rep} {M}x{N}x{Kd} {layout}: max err {(out - ref).abs().max().item()}"
         torch.cuda.synchronize()
     finally:
-        L.check(lib.vitk_set_option(b"dynamic_tiles", 0))
-    with pytest.raises(RuntimeError, match="unknown option"):
-        L.check(lib.vitk_set_option(b"no_such_option", 1))
+        K.set_dynamic_tiles(old)

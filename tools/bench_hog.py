@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vit_amd import _lib as L
 from vit_amd import kernels as K
 lib = L.load()
-L.check(lib.vitk_set_option(b"dynamic_tiles", int(os.environ.get("DYNAMIC_TILES", "1"))))   # DYNAMIC_TILES=0: fixed shares
+K.set_dynamic_tiles(os.environ.get("DYNAMIC_TILES", "1") != "0")   # DYNAMIC_TILES=0: fixed shares
 M, D, F = 256 * 272, 768, 3072
 def rnd(*s): return (torch.rand(*s, device="cuda") * 2 - 1).to(torch.bfloat16)
 a, w = rnd(M, D), rnd(2 * F, D)

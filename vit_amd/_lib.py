@@ -17,7 +17,7 @@ ACT_CODES = {"relu": 0, "reglu": 0, "silu": 1, "swiglu": 1, "gelu": 2, "geglu": 
 
 EXPORTS = [
     "vitk_version", "vitk_last_error", "vitk_norm_fwd", "vitk_norm_bwd", "vitk_norm_bwd_workspace_bytes",
-    "vitk_gemm", "vitk_gemm_workspace_bytes", "vitk_attn_fwd", "vitk_attn_bwd", "vitk_attn_weights", "vitk_rope_qk", "vitk_rope_rows", "vitk_debug_hold_cus", "vitk_set_option", "vitk_act_fwd",
+    "vitk_gemm", "vitk_gemm_workspace_bytes", "vitk_attn_fwd", "vitk_attn_bwd", "vitk_attn_weights", "vitk_rope_qk", "vitk_rope_rows", "vitk_debug_hold_cus", "vitk_act_fwd",
     "vitk_act_bwd", "vitk_im2col", "vitk_col2im", "vitk_colsum", "vitk_colsum_static", "vitk_colsum_workspace_bytes", "vitk_scale_cast",
 ]
 
@@ -34,7 +34,7 @@ class VitkGemm(C.Structure):
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32), ("algo", C.c_int32),
         ("act", C.c_int32), ("use_limit", C.c_int32), ("use_extra", C.c_int32), ("limit", C.c_float), ("extra_bias", C.c_float),
-        ("a_colsum", C.c_void_p),
+        ("a_colsum", C.c_void_p), ("dynamic_tiles", C.c_int32),
     ]
 
 
@@ -84,7 +84,6 @@ def load() -> C.CDLL:
         "vitk_attn_bwd": [C.POINTER(VitkAttn), vp],
         "vitk_attn_weights": [C.POINTER(VitkAttn), vp, vp],
         "vitk_debug_hold_cus": [i32, C.c_longlong, vp],
-        "vitk_set_option": [C.c_char_p, i32],
         "vitk_rope_qk": [vp, i32, vp, i64, i64, i64, i64, i64, i32, i32, i32, vp],
         "vitk_rope_rows": [vp, i32, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, vp],
         "vitk_act_fwd": [vp, vp, i32, i64, i64, i32, i32, i32, f32, i32, f32, f32, u64, vp],
@@ -96,6 +95,8 @@ def load() -> C.CDLL:
         "vitk_scale_cast": [vp, i32, i64, vp, vp, vp, i32, i64, i64, f32, f32, u64, vp],
     }
     for name, args in sigs.items():
+        if not hasattr(lib, name) and os.environ.get("VITK_LIB"):
+            continue   # an experimental build named by VITK_LIB may lack newer entry points
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = args

@@ -1,0 +1,699 @@
+// Shared pieces of the MFMA GEMM kernels: the epilogue description and functors, the tile walk, and the LDS-DMA
+// staging helpers.  Included by gemm.hip (128x128 and 256x256 tiles) and gemm2.hip (256x128 tiles, two blocks per CU).
+#pragma once
+#include "common.h"
+
+struct Epi {
+  void* out;
+  const void* bias;
+  const void* res;
+  const void* gamma;
+  const int64_t* row_idx;
+  void* aux;
+  const void* pos;
+  int64_t ldo, N, tokens, seq, prefix;
+  uint64_t seed;
+  float alpha, keep_scale;
+  uint32_t thr;
+  int act, use_limit, use_extra;
+  float limit, extra;
+  void* asum;            // A^T-layout products: asum[m] = sum over k of A[k, m] (dtype of out), or NULL
+  float* asum_partial;   // split-K: per-split partial sums [splits][M]
+  int64_t m_off;         // row of the whole problem that this launch's row 0 is (dropout stream index)
+};
+
+// sum of a fragment's 8 bf16 values added to s (4 x v_dot2c_f32_bf16 against ones)
+__device__ __forceinline__ float frag_sum(const bf16x8& f, float s) {
+  typedef __attribute__((ext_vector_type(2))) bf16 bf16x2_t;
+  bf16x2_t ones;
+  ones[0] = (bf16)1.f;
+  ones[1] = (bf16)1.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    bf16x2_t t;
+    t[0] = f[2 * j];
+    t[1] = f[2 * j + 1];
+    s = __builtin_amdgcn_fdot2_f32_bf16(t, ones, s, false);
+  }
+  return s;
+}
+// rows of the A operand summed over the block's K range, written by the waves that own the block's first column slice:
+// lane l and l+32 hold the two k-halves of row (l & 31) of each 32-row group
+template <int NI, int MODE, class TO>
+__device__ __forceinline__ void asum_store(const Epi& e, const float (&rs)[NI], int64_t mrow0, int64_t M, int64_t split, int lane) {
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const float s = rs[i] + __shfl_xor(rs[i], 32, 64);
+    const int64_t m = mrow0 + i * 32 + (lane & 31);
+    if (lane < 32 && m < M) {
+      if (MODE == -1) e.asum_partial[split * M + m] = s;
+      else ((TO*)e.asum)[m] = from_f<TO>(s);
+    }
+  }
+}
+
+
+constexpr int EPI_ACT = VITK_EPI_ACT, EPI_GLU = VITK_EPI_GLU, EPI_DACT = VITK_EPI_DACT, EPI_DGLU = VITK_EPI_DGLU;
+
+// Vector form used by the MFMA kernel: 4 consecutive columns n..n+3 of row m (n % 4 == 0).
+//   STORE / RESIDUAL / PATCH as EpiOp above;
+//   ACT   p = round(acc + bias) -> aux[m, n];  out[m, n] = dropout(act(p))                      (fc1, plain MLP)
+//   DACT  out[m, n] = dropmask * acc * act'(aux[m, n])                                          (fc2 dgrad, plain MLP)
+//   DGLU  acc = dh[m, f]; lin = aux[m, f], glu = aux[m, F + f];  out[m, f] = d lin, out[m, F + f] = d glu   (F = e.N)
+// (GLU forward pairs two column groups and has its own routine below.)
+// Per-row operands an epilogue reads from memory (residual row, position row, saved pre-activations).  They are
+// fetched for several rows before any of them is used, so the loads overlap instead of serialising on s_waitcnt.
+// Raw4<T>: 4 consecutive elements as loaded (no conversion until they are used, so a prefetched row costs 2 registers
+// for bf16 and 4 for fp32).
+template <class T> struct Raw4;
+template <> struct Raw4<float> {
+  float4 q;
+  __device__ __forceinline__ void load(const float* p) { q = *(const float4*)p; }
+  __device__ __forceinline__ float get(int j) const { return j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w; }
+};
+template <> struct Raw4<bf16> {
+  uint2 q;
+  __device__ __forceinline__ void load(const bf16* p) { q = *(const uint2*)p; }
+  __device__ __forceinline__ float get(int j) const {
+    const uint32_t w = j < 2 ? q.x : q.y;
+    return __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+};
+
+template <int MODE, class TO>
+struct EpiPre {
+  Raw4<bf16> a, b;   // PATCH: position row; DACT: pre-activations; DGLU: linear and gate pre-activations
+  Raw4<TO> r;        // RESIDUAL: the residual row
+  int64_t row;
+};
+
+template <int MODE, class TO>
+struct EpiVec {
+  typedef bf16 TI;
+  static __device__ __forceinline__ void prefetch(const Epi& e, int64_t m, int64_t n, EpiPre<MODE, TO>& p) {
+    if (MODE == VITK_EPI_RESIDUAL) {
+      p.row = e.row_idx ? e.row_idx[m] : m;
+      p.r.load((const TO*)e.res + p.row * e.ldo + n);
+    } else if (MODE == VITK_EPI_PATCH) {
+      if (e.pos) p.a.load((const TI*)e.pos + (m % e.tokens) * e.N + n);
+    } else if (MODE == EPI_DACT) {
+      p.a.load((const TI*)e.aux + m * e.N + n);
+    } else if (MODE == EPI_DGLU) {
+      p.a.load((const TI*)e.aux + m * 2 * e.N + n);
+      p.b.load((const TI*)e.aux + m * 2 * e.N + e.N + n);
+    }
+  }
+
+  // v = accumulators of columns n..n+3 of row m; bias/gamma = this lane's 4 columns (loaded once per tile)
+  static __device__ __forceinline__ void apply(const Epi& e, int64_t m, int64_t n, float (&v)[4], const float (&bias)[4],
+                                               const float (&gamma)[4], const EpiPre<MODE, TO>& p) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] += bias[j];
+    if (MODE == VITK_EPI_STORE) {
+      Vec4<TO> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.v[j] = v[j];
+      o.store((TO*)e.out + m * e.ldo + n);
+    } else if (MODE == VITK_EPI_RESIDUAL) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = round_as<TI>(v[j]);
+      if (e.thr) {   // one uniform branch for the vector, not one per element (a taken scalar branch costs a refetch)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
+      }
+      if (e.aux) {
+        Vec4<TI> a;
+#pragma unroll
+        for (int j = 0; j < 4; j++) a.v[j] = v[j];
+        a.store((TI*)e.aux + m * e.N + n);
+      }
+      Vec4<TO> r;
+      if (e.gamma) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[j] = p.r.get(j) + e.alpha * round_as<TO>(v[j] * gamma[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[j] = p.r.get(j) + e.alpha * v[j];
+      }
+      r.store((TO*)e.out + p.row * e.ldo + n);
+    } else if (MODE == VITK_EPI_PATCH) {
+      const int64_t b = m / e.tokens, t = m % e.tokens;
+      Vec4<TO> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        o.v[j] = round_as<TI>(v[j]);
+        if (e.pos) o.v[j] = round_as<TI>(o.v[j] + p.a.get(j));
+      }
+      o.store((TO*)e.out + (b * e.seq + e.prefix + t) * e.ldo + n);
+    } else if (MODE == EPI_ACT) {
+      Vec4<TI> pa;
+#pragma unroll
+      for (int j = 0; j < 4; j++) pa.v[j] = v[j];
+      pa.store((TI*)e.aux + m * e.N + n);
+      Vec4<TO> o;
+      ACT_SWITCH(e.act, ACT, {
+        _Pragma("unroll")
+        for (int j = 0; j < 4; j++) o.v[j] = act_apply_t<ACT>(round_as<TI>(v[j]));
+      });
+      if (e.thr) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          o.v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
+      }
+      o.store((TO*)e.out + m * e.ldo + n);
+    } else if (MODE == EPI_DACT) {
+      Vec4<TO> o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        v[j] = round_as<TI>(v[j]);
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+      }
+      ACT_SWITCH(e.act, ACT, {
+        _Pragma("unroll")
+        for (int j = 0; j < 4; j++) o.v[j] = v[j] * act_grad_t<ACT>(p.a.get(j));
+      });
+      o.store((TO*)e.out + m * e.ldo + n);
+    } else {  // EPI_DGLU: p.a = linear pre-activation, p.b = gate pre-activation
+      const int64_t F = e.N;
+      Vec4<TO> dl, dg;
+      float pl[4], pg[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        pl[j] = p.a.get(j);
+        pg[j] = p.b.get(j);
+        v[j] = round_as<TI>(v[j]);
+        if (e.thr) v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+        dl.v[j] = v[j];
+        dg.v[j] = v[j];
+        if (e.use_limit) {
+          const float l = pl[j], gl = pg[j];
+          dl.v[j] = (l >= -e.limit && l <= e.limit) ? dl.v[j] : 0.f;
+          dg.v[j] = (gl <= e.limit) ? dg.v[j] : 0.f;
+          pl[j] = fminf(fmaxf(l, -e.limit), e.limit);
+          pg[j] = fminf(gl, e.limit);
+        }
+        if (e.use_extra) pl[j] = round_as<TI>(pl[j] + e.extra);
+      }
+      ACT_SWITCH(e.act, ACT, {
+        _Pragma("unroll")
+        for (int j = 0; j < 4; j++) {
+          dl.v[j] *= round_as<TI>(act_apply_t<ACT>(pg[j]));
+          dg.v[j] *= pl[j] * act_grad_t<ACT>(pg[j]);
+        }
+      });
+      dl.store((TO*)e.out + m * e.ldo + n);
+      dg.store((TO*)e.out + m * e.ldo + F + n);
+    }
+  }
+};
+
+// GLU forward on a pair of column groups: lin[4] = fc1 columns f..f+3, glu[4] = columns F+f..F+f+3 of row m.
+//   aux[m, f] = lin + b, aux[m, F + f] = glu + b  (pre-activations, kept for backward);  out[m, f] = dropout(act(glu) * lin)
+template <class TO>
+__device__ __forceinline__ void epi_glu(const Epi& e, int64_t m, int64_t f, float (&lin)[4], float (&glu)[4],
+                                        const float (&bl)[4], const float (&bg)[4]) {
+  typedef bf16 TI;
+  const int64_t F = e.N / 2;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { lin[j] += bl[j]; glu[j] += bg[j]; }
+  Vec4<TI> pl, pg;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { pl.v[j] = lin[j]; pg.v[j] = glu[j]; }
+  pl.store((TI*)e.aux + m * e.N + f);
+  pg.store((TI*)e.aux + m * e.N + F + f);
+  Vec4<TO> o;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    lin[j] = round_as<TI>(lin[j]);
+    glu[j] = round_as<TI>(glu[j]);
+    if (e.use_limit) { lin[j] = fminf(fmaxf(lin[j], -e.limit), e.limit); glu[j] = fminf(glu[j], e.limit); }
+    if (e.use_extra) lin[j] = round_as<TI>(lin[j] + e.extra);
+  }
+  ACT_SWITCH(e.act, ACT, {
+_Pragma("unroll")
+    for (int j = 0; j < 4; j++) o.v[j] = round_as<TI>(act_apply_t<ACT>(glu[j])) * lin[j];
+  });
+  if (e.thr) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      o.v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + f + j)) >= e.thr ? round_as<TI>(o.v[j]) * e.keep_scale : 0.f;
+  }
+  o.store((TO*)e.out + m * e.ldo + f);
+}
+
+template <int MODE, class TI, class TO>
+struct EpiOp {
+  static __device__ __forceinline__ void apply(const Epi& e, int64_t m, int64_t n, float acc) {
+    float v = acc;
+    if (e.bias) v += to_f<TI>(((const TI*)e.bias)[n]);
+    if (MODE == VITK_EPI_STORE) {
+      ((TO*)e.out)[m * e.ldo + n] = from_f<TO>(v);
+    } else if (MODE == VITK_EPI_RESIDUAL) {
+      v = round_as<TI>(v);  // the linear's output as the compute dtype holds it
+      if (e.thr) v = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n)) >= e.thr ? round_as<TI>(v * e.keep_scale) : 0.f;
+      if (e.aux) ((TI*)e.aux)[m * e.N + n] = from_f<TI>(v);
+      const int64_t row = e.row_idx ? e.row_idx[m] : m;
+      if (e.gamma) v = round_as<TO>(v * to_f<TO>(((const TO*)e.gamma)[n]));
+      const float r = to_f<TO>(((const TO*)e.res)[row * e.ldo + n]);
+      ((TO*)e.out)[row * e.ldo + n] = from_f<TO>(r + e.alpha * v);
+    } else {  // PATCH
+      const int64_t b = m / e.tokens, t = m % e.tokens;
+      v = round_as<TI>(v);
+      if (e.pos) v = round_as<TI>(v + to_f<TI>(((const TI*)e.pos)[t * e.N + n]));
+      ((TO*)e.out)[(b * e.seq + e.prefix + t) * e.ldo + n] = from_f<TO>(v);
+    }
+  }
+};
+
+
+constexpr int BK = 64;
+constexpr int MODE_PARTIAL = -1;       // split-K: raw fp32 accumulators to the workspace
+constexpr int STG_LD = 68;             // epilogue staging: 32 rows x 64 floats per wave, rows padded to 68 floats
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// global -> registers for one operand tile. TR=false: rows x [k0,k0+64); TR=true: [k0,k0+64) x cols.
+// GLU forward: the block's 128 "virtual" fc1 columns are, per 64-column wave slice, 32 linear columns followed by
+// their 32 gate partners (weight rows F + f), so that a lane finds both halves of a pair in its own wave's tile.
+__device__ __forceinline__ int64_t glu_row(int64_t v, int64_t F) {
+  const int64_t f = (v >> 6) * 32 + (v & 31);
+  return (v & 32) ? F + f : f;
+}
+
+// Operand tiles are fetched with buffer loads: rows/columns outside the matrix are given an out-of-range offset and
+// come back as zeros, with no branch around the load.  voff = this thread's 4 chunk offsets (bytes) at the first
+// K-step, or OOB when the chunk's row (K-contiguous operand) / column (contraction-major operand) is outside.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr uint32_t OOB = 0xffffffffu;
+__device__ __forceinline__ uint32_t clip32(int64_t v) { return v > 0xfffffff0ll ? 0xfffffff0u : (uint32_t)v; }
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the MFMA kernels.  Accumulator element r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column
+// l&31 of a 32x32 tile; a wave transposes 32 rows x 64 columns at a time through its own LDS slab (row stride 68
+// floats) so that every lane then owns 4 consecutive columns: 16-byte loads of bias/residual, 8/16-byte stores,
+// whole 128-B lines per row.
+// ------------------------------------------------------------------------------------------------
+// ---- 8-column epilogues --------------------------------------------------------------------------
+// bf16 outputs move 8 consecutive columns per lane: 16-byte loads and stores, half as many memory instructions per
+// slab (the epilogues are paced by the issue of their stores).  Used by STORE with bf16 output, GLU and DGLU; their
+// arithmetic (and rounding points) is that of the 4-column forms above.
+template <int MODE, class TO>
+constexpr bool epi_wide() { return MODE == EPI_GLU || MODE == EPI_DGLU || (MODE == VITK_EPI_STORE && sizeof(TO) == 2); }
+
+struct Raw8 {   // 8 bf16 as loaded
+  uint4 q;
+  __device__ __forceinline__ void load(const bf16* p) { q = *(const uint4*)p; }
+  __device__ __forceinline__ float get(int j) const {
+    const uint32_t w = (j >> 1) == 0 ? q.x : (j >> 1) == 1 ? q.y : (j >> 1) == 2 ? q.z : q.w;
+    return __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+};
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; j++) t[j] = (bf16)v[j];
+  *(bf16x8*)p = t;
+}
+
+// GLU forward, 8 pairs: lin[8] = fc1 columns f..f+7, glu[8] = columns F+f..F+f+7 of row m (see epi_glu)
+__device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, float (&lin)[8], float (&glu)[8],
+                                         const float (&bl)[8], const float (&bg)[8]) {
+  typedef bf16 TI;
+  const int64_t F = e.N / 2;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { lin[j] += bl[j]; glu[j] += bg[j]; }
+  store8((TI*)e.aux + m * e.N + f, lin);
+  store8((TI*)e.aux + m * e.N + F + f, glu);
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    lin[j] = round_as<TI>(lin[j]);
+    glu[j] = round_as<TI>(glu[j]);
+  }
+  if (e.use_limit || e.use_extra) {   // off in the usual configuration: a real (uniform) branch, not selects per element
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (e.use_limit) { lin[j] = fminf(fmaxf(lin[j], -e.limit), e.limit); glu[j] = fminf(glu[j], e.limit); }
+      if (e.use_extra) lin[j] = round_as<TI>(lin[j] + e.extra);
+    }
+  }
+  ACT_SWITCH(e.act, ACT, {
+_Pragma("unroll")
+    for (int j = 0; j < 8; j++) o[j] = round_as<TI>(act_apply_t<ACT>(glu[j])) * lin[j];
+  });
+  if (e.thr) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + f + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
+  }
+  store8((TI*)e.out + m * e.ldo + f, o);
+}
+
+// DGLU, 8 columns: v = dh[m, n..n+7]; pa / pb = saved linear / gate pre-activations (see EpiVec, EPI_DGLU)
+__device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, float (&v)[8], const Raw8& pa, const Raw8& pb) {
+  typedef bf16 TI;
+  const int64_t F = e.N;
+  float dl[8], dg[8], pl[8], pg[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    pl[j] = pa.get(j);
+    pg[j] = pb.get(j);
+    v[j] = round_as<TI>(v[j]);
+  }
+  if (e.thr) {   // one uniform branch for the vector, not one per element
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    dl[j] = v[j];
+    dg[j] = v[j];
+  }
+  if (e.use_limit || e.use_extra) {   // a real (uniform) branch: see epi_glu8
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (e.use_limit) {
+        const float l = pl[j], gl = pg[j];
+        dl[j] = (l >= -e.limit && l <= e.limit) ? dl[j] : 0.f;
+        dg[j] = (gl <= e.limit) ? dg[j] : 0.f;
+        pl[j] = fminf(fmaxf(l, -e.limit), e.limit);
+        pg[j] = fminf(gl, e.limit);
+      }
+      if (e.use_extra) pl[j] = round_as<TI>(pl[j] + e.extra);
+    }
+  }
+  ACT_SWITCH(e.act, ACT, {
+    _Pragma("unroll")
+    for (int j = 0; j < 8; j++) {
+      dl[j] *= round_as<TI>(act_apply_t<ACT>(pg[j]));
+      dg[j] *= pl[j] * act_grad_t<ACT>(pg[j]);
+    }
+  });
+  store8((TI*)e.out + m * e.ldo + n, dl);
+  store8((TI*)e.out + m * e.ldo + F + n, dg);
+}
+
+template <int MODE, class TO>
+struct EpiCols {  // per-lane column constants, loaded once per tile
+  float bias0[4], bias1[4], gam[4];
+  float wb0[8], wb1[8];   // 8-column forms
+  int64_t ncol;   // first of this lane's 4 (or 8) output columns (GLU: the linear column f)
+  __device__ __forceinline__ void init(const Epi& e, int64_t nwave, int64_t N, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { bias0[j] = 0.f; bias1[j] = 0.f; gam[j] = 1.f; }
+    if (epi_wide<MODE, TO>()) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { wb0[j] = 0.f; wb1[j] = 0.f; }
+      if (MODE == EPI_GLU) {
+        const int cv = lane & 3;
+        ncol = (nwave >> 6) * 32 + 8 * cv;
+        if (e.bias && nwave + 8 * cv < N) {
+          Raw8 bl, bg;
+          bl.load((const bf16*)e.bias + ncol);
+          bg.load((const bf16*)e.bias + (N >> 1) + ncol);
+#pragma unroll
+          for (int j = 0; j < 8; j++) { wb0[j] = bl.get(j); wb1[j] = bg.get(j); }
+        }
+      } else {
+        ncol = nwave + 8 * (lane & 7);
+        if (e.bias && ncol < N) {
+          Raw8 b;
+          b.load((const bf16*)e.bias + ncol);
+#pragma unroll
+          for (int j = 0; j < 8; j++) wb0[j] = b.get(j);
+        }
+      }
+    } else if (MODE == EPI_GLU) {
+      const int cv = lane & 7;
+      ncol = (nwave >> 6) * 32 + 4 * cv;
+      if (e.bias && nwave + 4 * cv < N) {
+        Vec4<bf16> bl, bg;
+        bl.load((const bf16*)e.bias + ncol);
+        bg.load((const bf16*)e.bias + (N >> 1) + ncol);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { bias0[j] = bl.v[j]; bias1[j] = bg.v[j]; }
+      }
+    } else {
+      ncol = nwave + 4 * (lane & 15);
+      if (MODE != MODE_PARTIAL && ncol < N) {
+        if (e.bias) {
+          Vec4<bf16> b; b.load((const bf16*)e.bias + ncol);
+#pragma unroll
+          for (int j = 0; j < 4; j++) bias0[j] = b.v[j];
+        }
+        if (MODE == VITK_EPI_RESIDUAL && e.gamma) {
+          Vec4<TO> g; g.load((const TO*)e.gamma + ncol);
+#pragma unroll
+          for (int j = 0; j < 4; j++) gam[j] = g.v[j];
+        }
+      }
+    }
+  }
+};
+
+// One 32-row x 64-column slab of a wave's tile, in three steps so that a kernel can issue the memory reads of a slab
+// (residual / position / saved pre-activation rows) well before it needs them:
+//   slab_prefetch  loads of the slab's 8 rows per lane;  slab_stage  accumulators -> the wave's own LDS slab;
+//   slab_finish    read back 4 consecutive columns per lane, apply the epilogue, store.
+// The staging slab belongs to one wave and LDS operations of a wave complete in order, so no barrier is needed
+// between the steps (the caller has one block barrier between the last main-loop LDS read and the first stage).
+template <int MODE, class TO>
+struct SlabPre {
+  EpiPre<(MODE < 0 ? 0 : MODE), TO> r[8];
+  Raw8 wa[4], wb[4];   // 8-column DGLU: 4 rows per lane, linear and gate pre-activations
+};
+
+template <int MODE>
+constexpr bool epi_reads_memory() { return MODE == VITK_EPI_RESIDUAL || MODE == VITK_EPI_PATCH || MODE == EPI_DACT || MODE == EPI_DGLU; }
+
+template <int MODE, class TO>
+__device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, TO>& cols, SlabPre<MODE, TO>& pre,
+                                              int64_t mbase, int64_t M, int64_t N, int lane) {
+  if (!epi_reads_memory<MODE>()) return;
+  constexpr int EMODE = MODE < 0 ? 0 : MODE;
+  if (epi_wide<MODE, TO>()) {   // DGLU
+    const int rr = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int64_t m = mbase + it * 8 + rr;
+      if (m < M && cols.ncol < N) {
+        pre.wa[it].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol);
+        pre.wb[it].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol);
+      }
+    }
+    return;
+  }
+  const int rr = lane >> 4;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int64_t m = mbase + it * 4 + rr;
+    if (m < M && cols.ncol < N) EpiVec<EMODE, TO>::prefetch(e, m, cols.ncol, pre.r[it]);
+  }
+}
+
+__device__ __forceinline__ void slab_stage(float* stg, const f32x16& a0, const f32x16& a1, int lane) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    stg[row * STG_LD + (lane & 31)] = a0[r];
+    stg[row * STG_LD + 32 + (lane & 31)] = a1[r];
+  }
+}
+
+template <int MODE, class TO>
+__device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO>& cols, const SlabPre<MODE, TO>& pre,
+                                            const float* stg, int64_t mbase, int64_t nwave, int64_t M, int64_t N,
+                                            int64_t split, float* __restrict__ partial, int lane) {
+  constexpr int EMODE = MODE < 0 ? 0 : MODE;
+  const int64_t ncol = cols.ncol;
+  if (epi_wide<MODE, TO>() && MODE == EPI_GLU) {
+    const int cv = lane & 3, rr = lane >> 2;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int row = it * 16 + rr;
+      const int64_t m = mbase + row;
+      float lin[8], glu[8];
+      *(float4*)lin = *(const float4*)(stg + row * STG_LD + 8 * cv);
+      *(float4*)(lin + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
+      *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv);
+      *(float4*)(glu + 4) = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv + 4);
+      if (m < M && nwave + 8 * cv < N) epi_glu8(e, m, ncol, lin, glu, cols.wb0, cols.wb1);
+    }
+  } else if (epi_wide<MODE, TO>()) {
+    const int cv = lane & 7, rr = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + rr;
+      const int64_t m = mbase + row;
+      float v[8];
+      *(float4*)v = *(const float4*)(stg + row * STG_LD + 8 * cv);
+      *(float4*)(v + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
+      if (m < M && ncol < N) {
+        if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, v, pre.wa[it], pre.wb[it]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
+          store8((bf16*)e.out + m * e.ldo + ncol, v);
+        }
+      }
+    }
+  } else if (MODE == EPI_GLU) {
+    const int cv = lane & 7, rr = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = it * 8 + rr;
+      const int64_t m = mbase + row;
+      float lin[4], glu[4];
+      *(float4*)lin = *(const float4*)(stg + row * STG_LD + 4 * cv);
+      *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 4 * cv);
+      if (m < M && nwave + 4 * cv < N) epi_glu<TO>(e, m, ncol, lin, glu, cols.bias0, cols.bias1);
+    }
+  } else {
+    const int cv = lane & 15, rr = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 4 + rr;
+      const int64_t m = mbase + row;
+      float v[4];
+      *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
+      if (m < M && ncol < N) {
+        if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + ncol) = *(const float4*)v;
+        else EpiVec<EMODE, TO>::apply(e, m, ncol, v, cols.bias0, cols.gam, pre.r[it]);
+      }
+    }
+  }
+}
+
+// blocks that share an XCD (bid % 8) get consecutive tile ids, so one L2 sees neighbouring tiles
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
+  const int64_t xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Tile order inside one split: panels of PANEL_M row tiles, walked column tile by column tile.  The blocks of an XCD
+// run consecutive tile ids, so at any time they share a few B column tiles and one panel of A rows, and each B tile is
+// fetched into that XCD's L2 once per panel instead of once per row tile.
+#ifndef PANEL_M_VALUE
+#define PANEL_M_VALUE 8
+#endif
+constexpr int PANEL_M = PANEL_M_VALUE;
+__device__ __forceinline__ void tile_coords(int64_t wg, int64_t tiles_m, int64_t tiles_n, int64_t& tm, int64_t& tn, int64_t& split) {
+  const int64_t per_split = tiles_m * tiles_n;
+  split = wg / per_split;
+  const int64_t r = wg - split * per_split;
+  const int64_t per_panel = PANEL_M * tiles_n;
+  const int64_t panel = r / per_panel, in_panel = r - panel * per_panel;
+  const int64_t rows_here = tiles_m - panel * PANEL_M < PANEL_M ? tiles_m - panel * PANEL_M : PANEL_M;
+  tm = panel * PANEL_M + in_panel % rows_here;
+  tn = in_panel / rows_here;
+}
+
+constexpr int HS_B = 16384;        // one operand's half-stage
+constexpr int SLOT_B = 2 * HS_B;   // A then B
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ int swz_rows(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }            // G[(r>>2)&3]
+__device__ __forceinline__ int swz_krow(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+struct DmaSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[2];   // this lane's two 16-byte units at half-stage 0 (byte offsets), or OOB
+  int32_t klim[2];    // K-contiguous operand: unit valid while kk < klim
+  uint32_t hstride;   // bytes per half-stage
+};
+
+template <bool TR, bool GLUMAP>
+__device__ __forceinline__ DmaSrc make_dma(const bf16* __restrict__ g, int64_t ld, int64_t row0, int64_t nrows, int64_t kbeg,
+                                           int64_t kend, int64_t Ktot, int wid, int lane) {
+  DmaSrc t;
+  if (!TR) {
+    const int64_t base_row = GLUMAP ? 0 : row0;
+    const int64_t span_rows = GLUMAP ? nrows : (nrows - row0 < 256 ? nrows - row0 : 256);
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + base_row * ld), 0, clip32(((span_rows - 1) * ld + Ktot) * 2), 0x00020000);
+    t.hstride = 64;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int p = (wid * 2 + j) * 64 + lane;
+      const int row = p >> 2, c = (p & 3) ^ swz_rows(row);
+      const int64_t r = row0 + row;
+      const int64_t rr = GLUMAP ? glu_row(r, nrows >> 1) : (int64_t)row;
+      t.voff[j] = r < nrows ? (uint32_t)((rr * ld + kbeg + c * 8) * 2) : OOB;
+      t.klim[j] = (int32_t)(kend - kbeg) - c * 8;
+    }
+  } else {
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + kbeg * ld + row0), 0,
+                                               clip32(((kend - kbeg - 1) * ld + (nrows - row0)) * 2), 0x00020000);
+    t.hstride = (uint32_t)(32 * ld * 2);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int p = (wid * 2 + j) * 64 + lane;
+      const int krow = p >> 5, col = ((p & 31) ^ (swz_krow(krow) << 1)) * 8;
+      t.voff[j] = row0 + col < nrows ? (uint32_t)(((int64_t)krow * ld + col) * 2) : OOB;
+      t.klim[j] = 0x7fffffff;
+    }
+  }
+  return t;
+}
+
+// request half-stage h (k offset 32*h from the block's first k) of one operand into `dst`
+// The compiler knows these requests write LDS and drains them (s_waitcnt vmcnt(0)) in front of the next LDS read it
+// issues, whichever slot that read addresses.  Issuing them from inline assembly instead keeps three half-stages in flight
+// across the fragment reads; measured on one device against this form, that was no faster on any layout and 6 % slower
+// on weight gradients (both operands stream from HBM there, and workgroups that run closer together share more lines in
+// L2), so the plain form stays.
+template <bool TR>
+__device__ __forceinline__ void dma_half(const DmaSrc& t, char* dst, int wid, int h) {
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    uint32_t off = t.voff[j] + (uint32_t)h * t.hstride;
+    if (!TR) off = (h * 32 < t.klim[j] && t.voff[j] != OOB) ? off : OOB;
+    else off = t.voff[j] != OOB ? off : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rsrc, (lds_void_t*)(dst + (wid * 2 + j) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+// 16x16x32 operand fragment from a DMA-staged half-stage: index r0 + (lane & 15) (r0 a multiple of 16),
+// k = 8*(lane>>4) + j
+template <bool TR, int PITCH = 512>   // PITCH = bytes per k-row of a contraction-major image
+__device__ __forceinline__ bf16x8 read_frag16(const char* hs, int r0, int lane) {
+  if (!TR) {
+    const int row = r0 + (lane & 15);
+    return *(const bf16x8*)(hs + row * 64 + (((lane >> 4) ^ swz_rows(row)) << 4));
+  } else {
+    const int i = lane & 15;
+    const int krow = 8 * (lane >> 4) + (i >> 2);
+    const char* p = hs + krow * PITCH + ((((r0 >> 4) ^ swz_krow(krow))) << 5) + 8 * (i & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * PITCH));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+}
+
+// barrier that leaves DMA requests in flight: only the half-stage read next has to be complete
+__device__ __forceinline__ void dma_barrier(bool drain_reads) {
+  __builtin_amdgcn_sched_barrier(0);
+  if (drain_reads) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// 32-row x 64-column slab (row tiles 2s, 2s+1 of a wave's 8 x 4 grid of 16x16 accumulators) -> the wave's LDS slab.
+// Accumulator register r of lane l is row 4*(l>>4) + r, column l&15 of its tile.
+__device__ __forceinline__ void slab_stage16(float* stg, const f32x4_t (&acc)[8][4], int s, int lane) {
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        stg[(16 * h + 4 * (lane >> 4) + r) * STG_LD + 16 * j + (lane & 15)] = acc[2 * s + h][j][r];
+}

@@ -30,7 +30,6 @@ def set_dynamic_tiles(on: bool) -> bool:
     run on a side stream beside the GEMMs and hold CUs meanwhile.  Returns the previous setting."""
     global _DYNAMIC_TILES
     old, _DYNAMIC_TILES = _DYNAMIC_TILES, bool(on)
-    L.check(L.load().vitk_set_option(b"dynamic_tiles", int(_DYNAMIC_TILES)))
     return old
 
 
@@ -139,6 +138,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     g.in_dtype, g.out_dtype = L.dt(a), L.dt(out)
     g.epilogue = epilogue
     g.algo = _ALGO if algo is None else algo
+    g.dynamic_tiles = int(_DYNAMIC_TILES)
     g.workspace, g.workspace_bytes = None, 0
     need = lib.vitk_gemm_workspace_bytes(C.byref(g))
     if need:

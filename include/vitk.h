@@ -204,6 +204,13 @@ int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const int64_t* a
 int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, void* out,
                     int out_dtype, int64_t rows, int64_t N, float alpha, float drop_p, uint64_t seed, void* stream);
 
+/* ---- prefix tokens (vit/vit.py:500-505: torch.cat([cls_tokens.expand(B), register_tokens.expand(B), x], dim=1)) ----
+ * out is the [B, S, D] sequence whose rows ncls + nreg .. S - 1 the patch-embedding GEMM writes (VITK_EPI_PATCH with
+ * seq = S, prefix = ncls + nreg); this call fills rows 0 .. ncls + nreg - 1 of every sample with the learned tokens
+ * cls [ncls, D] and reg [nreg, D] (both of prefix_dtype), cast to out_dtype.  D % 4 == 0. */
+int vitk_prefix_fill(const void* cls, int64_t ncls, const void* reg, int64_t nreg, int prefix_dtype, void* out, int out_dtype,
+                     int64_t B, int64_t S, int64_t D, void* stream);
+
 /* Diagnostics (no counterpart in the reference): `blocks` idle workgroups that hold their CUs for about `cycles` shader
  * clocks, to measure what a launch loses when another stream's kernel occupies part of the chip. */
 int vitk_debug_hold_cus(int blocks, long long cycles, void* stream);

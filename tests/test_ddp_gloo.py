@@ -67,7 +67,38 @@ def _worker(rank: int, world: int, port: int, q):
         for i, p in enumerate(params):
             expect = sum((r + 1) + 2.0 for r in range(world)) / world
             assert torch.allclose(p.grad, torch.full_like(p, expect)), ("accum", i, p.grad[:3], expect)
+        # gradient sinks: a backward that asks for the bucket slice of its parameter and produces the gradient there;
+        # autograd adopts the slice as .grad, the hook finds it in place and copies nothing
+        from vit_amd.ddp import grad_sink
+
+        class ScaleFn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, p, c):
+                ctx.c, ctx.ptr = c, p.data_ptr()
+                return p.detach() * c
+
+            @staticmethod
+            def backward(ctx, g):
+                out = grad_sink(ctx.ptr, g.shape, g.dtype)
+                assert out is not None
+                torch.mul(g, ctx.c, out=out)
+                return out, None
+
+        for p in params + [unused]:
+            p.grad = None
+        target = params[2]
+        b, i = red._where[target]
+        slot = red._view(b, i)
+        (ScaleFn.apply(target, float(rank + 1)).sum() + sum(p.sum() for p in params if p is not target)).backward()
+        assert target.grad.data_ptr() == slot.data_ptr()          # adopted, not copied
+        assert grad_sink(target.data_ptr(), target.shape, target.dtype) is None   # handed out once per step
+        red.finish()
+        expect = sum(r + 1 for r in range(world)) / world
+        assert torch.allclose(target.grad, torch.full_like(target, expect)), ("sink", target.grad[:3], expect)
+        with red.no_sync():
+            assert grad_sink(target.data_ptr(), target.shape, target.dtype) is None   # accumulation: no sinks
         red.remove()
+        assert grad_sink(target.data_ptr(), target.shape, target.dtype) is None
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback

@@ -487,3 +487,67 @@ def test_state_dict_layout_and_frozen_blocks():
             assert p.grad is None, k
         elif p.numel() and p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_parameter_copies_follow_in_place_updates():
+    """Under autocast the bf16 copies of the fp32 weights are kept between steps; an in-place update of a parameter
+    (what an optimizer step or load_state_dict does) must be seen by the next forward."""
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=2, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="fourier",
+                    num_register_tokens=2, dtype=torch.float32)
+    model = cfg.instantiate(device=DEV)
+    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=3), seed=4)
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    x = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(0)).to(DEV)
+
+    def fwd(m):
+        m.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return m(x).dense_features.float()
+
+    first = fwd(model)
+    assert torch.equal(first, fwd(model))            # second call runs on the kept copies
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.25)
+    updated = fwd(model)
+    assert not torch.equal(first, updated)
+    fresh = cfg.instantiate(device=DEV)               # never seen before: no copies to reuse
+    fresh.load_state_dict(model.state_dict(), strict=True)
+    assert torch.equal(updated, fwd(fresh))
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    assert torch.equal(first, fwd(model))
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_sequence_written_by_patch_embedding_equals_concatenation(autocast):
+    """ViT.forward lets the patch-embedding GEMM write behind the prefix tokens (vit/vit.py:500-505); values and
+    gradients must equal patch embedding followed by the concatenation, bit for bit."""
+    from vit_amd import ops
+
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 48), depth=1, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="fourier",
+                    num_register_tokens=3, num_cls_tokens=1, dtype=torch.float32)
+    model = cfg.instantiate(device=DEV)
+    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=5), seed=6)
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    x = torch.randn(4, 3, 32, 48, generator=torch.Generator().manual_seed(1)).to(DEV)
+    w = torch.randn(4, 4 + 24, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    results = []
+    for fused in (True, False):
+        model.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            if fused:
+                seq = model.stem(xg, prefix=(model.cls_tokens, model.register_tokens))
+            else:
+                seq = ops.concat_prefix(model.cls_tokens, model.register_tokens, model.stem(xg))
+        (seq.float() * w).sum().backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        results.append((seq.detach(), xg.grad, grads))
+    (s1, g1, p1), (s2, g2, p2) = results
+    assert s1.dtype == s2.dtype == torch.float32 and s1.shape == s2.shape == (4, 28, 64)
+    assert torch.equal(s1, s2) and torch.equal(g1, g2)
+    assert set(p1) == set(p2) and {"cls_tokens", "register_tokens", "stem.patch.weight"} <= set(p1)
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k

@@ -845,6 +845,49 @@ extern "C" int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const in
 }
 
 // ------------------------------------------------------------------------------------------------
+// prefix tokens (vit/vit.py:500-505: cat([cls, register, patches], dim=1) with the learned tokens expanded over the
+// batch): out[b, r, :] = cls[r, :] for r < ncls, reg[r - ncls, :] for ncls <= r < ncls + nreg, cast to the dtype of the
+// sequence.  Rows from ncls + nreg on belong to the patch tokens and are written by the patch-embedding GEMM.
+// ------------------------------------------------------------------------------------------------
+template <class TP, class TO>
+__global__ __launch_bounds__(256) void prefix_fill_k(const TP* __restrict__ cls, const TP* __restrict__ reg,
+                                                     TO* __restrict__ out, int64_t B, int64_t ncls, int64_t nreg, int64_t S,
+                                                     int64_t D) {
+  const int64_t npre = ncls + nreg, dv = D / 4;
+  const int64_t nvec = B * npre * dv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t c = (i % dv) * 4;
+    const int64_t r = (i / dv) % npre;
+    const int64_t b = i / (dv * npre);
+    Vec4<TP> v;
+    v.load(r < ncls ? cls + r * D + c : reg + (r - ncls) * D + c);
+    Vec4<TO> o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o.v[j] = v.v[j];
+    o.store(out + (b * S + r) * D + c);
+  }
+}
+
+extern "C" int vitk_prefix_fill(const void* cls, int64_t ncls, const void* reg, int64_t nreg, int prefix_dtype, void* out,
+                                int out_dtype, int64_t B, int64_t S, int64_t D, void* stream) {
+  VITK_REQUIRE(out && ncls >= 0 && nreg >= 0 && (cls || ncls == 0) && (reg || nreg == 0), "prefix_fill: null pointer");
+  VITK_REQUIRE(D > 0 && D % 4 == 0, "prefix_fill: D=%lld must be a multiple of 4", (long long)D);
+  VITK_REQUIRE(S >= ncls + nreg && B >= 0, "prefix_fill: S=%lld shorter than the %lld prefix rows", (long long)S,
+               (long long)(ncls + nreg));
+  if (B * (ncls + nreg) == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_grid(B * (ncls + nreg) * (D / 4))), block(256);
+  DISPATCH_DTYPE(prefix_dtype, TP, {
+    DISPATCH_DTYPE(out_dtype, TO, {
+      hipLaunchKernelGGL((prefix_fill_k<TP, TO>), grid, block, 0, st, (const TP*)cls, (const TP*)reg, (TO*)out, B, ncls, nreg,
+                         S, D);
+    });
+  });
+  VITK_LAUNCH_CHECK("prefix_fill");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Diagnostics: `blocks` workgroups of one wave per SIMD that stay resident for about `cycles` shader clocks and do
 // nothing -- a stand-in for a collective's kernel on a side stream, to see what a launch on the main stream loses when
 // some CUs are taken (tools/bench_hog.py).  The loop is bounded by the clock AND by an iteration count.

@@ -632,9 +632,21 @@ static int pick_splits(const VitkGemm* g) {
   return (int)best;
 }
 
+constexpr size_t TILE_CTR_BYTES = 256;
+static size_t partial_bytes(const VitkGemm* g, int splits) {
+  return splits > 1 ? (size_t)splits * (size_t)g->M * ((size_t)g->N + (g->a_colsum ? 1 : 0)) * sizeof(float) : 0;
+}
+static int64_t ragged_round_cut(const VitkGemm* g);
 extern "C" size_t vitk_gemm_workspace_bytes(const VitkGemm* g) {
   if (!g) return 0;
   if (!mfma_ok(g) || g->algo == 1) return g->a_colsum ? vitk_colsum_workspace_bytes(g->M) : 0;   // separate column-sum pass
+  if (const int64_t m1 = ragged_round_cut(g)) {   // the rows after the cut are a problem of their own, usually split along K
+    VitkGemm tail = *g;
+    tail.M = g->M - m1;
+    tail.algo = 4;
+    const size_t part = partial_bytes(&tail, pick_splits(&tail));
+    return g->dynamic_tiles ? (part + 255) / 256 * 256 + 256 : part;
+  }
   const int s = pick_splits(g);
   const size_t part = s > 1 ? (size_t)s * (size_t)g->M * ((size_t)g->N + (g->a_colsum ? 1 : 0)) * sizeof(float) : 0;
   return g->dynamic_tiles && use_tile256(g) ? (part + 255) / 256 * 256 + 256 : part;   // + the tile counters
@@ -701,10 +713,6 @@ static int64_t gemm_blocks() {
 // from counters when the caller sets VitkGemm::dynamic_tiles because it expects another stream's kernels to hold CUs
 // during the launch (data-parallel training: the gradient all-reduce runs beside the backward pass).  The counters are
 // the last TILE_CTR_BYTES of the workspace.
-constexpr size_t TILE_CTR_BYTES = 256;
-static size_t partial_bytes(const VitkGemm* g, int splits) {
-  return splits > 1 ? (size_t)splits * (size_t)g->M * ((size_t)g->N + (g->a_colsum ? 1 : 0)) * sizeof(float) : 0;
-}
 static unsigned int* tile_counters(const VitkGemm* g, int splits, hipStream_t st) {
   if (!g->dynamic_tiles || !g->workspace) return nullptr;
   const size_t off = (partial_bytes(g, splits) + 255) / 256 * 256;

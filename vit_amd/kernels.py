@@ -359,12 +359,29 @@ def colsum(a: Tensor, rows: int, N: int, lda: int, out_dtype: torch.dtype, *, a_
 
 
 def scale_cast(g: Tensor, rows: int, N: int, out_dtype: torch.dtype, *, row_idx: Optional[Tensor] = None,
-               gamma: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0) -> Tensor:
+               gamma: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
+               ldg: Optional[int] = None) -> Tensor:
+    """``ldg``: elements between consecutive rows of ``g`` (default N); with it ``g`` may be a view whose rows are
+    N contiguous elements ldg apart."""
     lib = L.load()
     L.require_gpu(g, gamma, row_idx)
-    g = _c(g)
+    if ldg is None:
+        g, ldg = _c(g), N
     assert gamma is None or gamma.dtype == g.dtype
     out = torch.empty((rows, N), dtype=out_dtype, device=g.device)
-    L.check(lib.vitk_scale_cast(L.ptr(g), L.dt(g), N, L.ptr(row_idx), L.ptr(gamma), L.ptr(out), L.dt(out), rows, N, alpha,
+    L.check(lib.vitk_scale_cast(L.ptr(g), L.dt(g), ldg, L.ptr(row_idx), L.ptr(gamma), L.ptr(out), L.dt(out), rows, N, alpha,
                                 drop_p, seed & 0xFFFFFFFFFFFFFFFF, L.stream()))
+    return out
+
+
+def prefix_fill_(out: Tensor, cls_tokens: Tensor, register_tokens: Tensor) -> Tensor:
+    """Rows 0 .. ncls + nreg - 1 of every sample of out [B, S, D] <- cls [1, ncls, D], register tokens [1, nreg, D]."""
+    lib = L.load()
+    L.require_gpu(out, cls_tokens, register_tokens)
+    B, S, D = out.shape
+    ncls, nreg = cls_tokens.shape[1], register_tokens.shape[1]
+    assert out.is_contiguous() and cls_tokens.dtype == register_tokens.dtype
+    cls_tokens, register_tokens = _c(cls_tokens), _c(register_tokens)
+    L.check(lib.vitk_prefix_fill(L.ptr(cls_tokens) if ncls else None, ncls, L.ptr(register_tokens) if nreg else None, nreg,
+                                 L.dt(cls_tokens), L.ptr(out), L.dt(out), B, S, D, L.stream()))
     return out

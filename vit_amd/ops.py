@@ -10,12 +10,14 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
 from torch import Tensor
 
 from . import _lib as L
+from . import ddp as _ddp
 from . import kernels as K
 
 
@@ -64,9 +66,49 @@ def _cast(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
     return (t if t.dtype == dtype else t.to(dtype)).contiguous()
 
 
+# Compute-dtype copies of parameters (fp32 master weights under autocast), kept until the parameter changes: an
+# in-place update (optimizer step, load_state_dict) bumps ``_version``, a replaced ``.data`` changes the address.  One
+# entry per parameter object; the entry dies with the parameter.
+_PARAM_COPIES: dict = {}
+
+
+def _cast_param(t: Optional[Tensor], dtype: torch.dtype, make=None) -> Optional[Tensor]:
+    """``_cast`` for parameters, cached per parameter.  ``make(t)`` builds the copy when it is not a plain cast (the
+    zero-padded patch-embedding weight)."""
+    if t is None:
+        return None
+    if make is None and t.dtype == dtype:
+        return t.detach().contiguous()
+    key = (t._version, t.data_ptr(), dtype, tuple(t.shape))
+    ent = _PARAM_COPIES.get(id(t))
+    if ent is not None and ent[0]() is t and ent[1] == key:
+        return ent[2]
+    c = make(t.detach()) if make is not None else t.detach().to(dtype).contiguous()
+    ident = id(t)
+    _PARAM_COPIES[ident] = (weakref.ref(t, lambda _r, ident=ident: _PARAM_COPIES.pop(ident, None)), key, c)
+    return c
+
+
+def _ptrs(*params: Optional[Tensor]) -> tuple:
+    """Storage addresses of master parameters, kept by a forward pass for its backward's gradient sinks."""
+    return tuple(None if p is None else p.data_ptr() for p in params)
+
+
+def _grad_buffer(param_ptr: Optional[int], shape, dtype: torch.dtype, device) -> Tensor:
+    """Where a parameter's gradient is produced: the slice of the data-parallel reducer's bucket when one is attached
+    to the parameter (autograd adopts it as ``.grad`` without a copy), else fresh memory."""
+    if param_ptr is not None and _ddp._SINKS:
+        sink = _ddp.grad_sink(param_ptr, shape, dtype)
+        if sink is not None:
+            return sink
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
 def _linear_bwd(dy: Tensor, inp: Tensor, w_c: Tensor, need_dx: bool, need_dw: bool, need_db: bool, wdtype: torch.dtype,
-                dx_dtype: Optional[torch.dtype] = None, tag: str = ""):
-    """Backward of y = inp @ w^T + b.  dy [M,N], inp [M,Kin], w_c [N,Kin] (compute dtype)."""
+                dx_dtype: Optional[torch.dtype] = None, tag: str = "", w_ptr: Optional[int] = None,
+                b_ptr: Optional[int] = None):
+    """Backward of y = inp @ w^T + b.  dy [M,N], inp [M,Kin], w_c [N,Kin] (compute dtype).  ``w_ptr`` / ``b_ptr``: storage
+    addresses of the master weight / bias (keys of the reducer's gradient sinks)."""
     M, N = dy.shape
     Kin = inp.shape[1]
     dx = dw = db = None
@@ -74,9 +116,9 @@ def _linear_bwd(dy: Tensor, inp: Tensor, w_c: Tensor, need_dx: bool, need_dw: bo
         dx = torch.empty((M, Kin), dtype=dx_dtype or dy.dtype, device=dy.device)
         K.gemm(dy, w_c, trans_a=False, trans_b=True, M=M, N=Kin, K=N, out=dx, tag=tag + ".dgrad")
     if need_dw:
-        dw = torch.empty((N, Kin), dtype=wdtype, device=dy.device)
+        dw = _grad_buffer(w_ptr, (N, Kin), wdtype, dy.device)
         if need_db:  # the bias gradient dy.sum(0) comes out of the weight-gradient pass over dy
-            db = torch.empty((N,), dtype=wdtype, device=dy.device)
+            db = _grad_buffer(b_ptr, (N,), wdtype, dy.device)
         K.gemm(dy, inp, trans_a=True, trans_b=True, M=N, N=Kin, K=M, out=dw, a_colsum=db, tag=tag + ".wgrad")
     elif need_db:
         db = K.colsum(dy, M, N, N, wdtype)
@@ -126,7 +168,7 @@ class LinearFn(torch.autograd.Function):
         L.require_gpu(x, w)
         shape = x.shape
         x2 = _cast(x.reshape(-1, shape[-1]), tc)
-        wc, bc = _cast(w, tc), _cast(b, tc)
+        wc, bc = _cast_param(w, tc), _cast_param(b, tc)
         M, Kin, N = x2.shape[0], x2.shape[1], w.shape[0]
         y = torch.empty((M, N), dtype=tc, device=x.device)
         K.gemm(x2, wc, trans_a=False, trans_b=False, M=M, N=N, K=Kin, out=y, bias=bc)
@@ -201,38 +243,42 @@ def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, 
 
 # The gradient of the residual stream leaves one sub-layer's norm backward in fp32 and is the first thing the previous
 # sub-layer casts to bf16 (when there is no layer scale, drop-path or dropout to apply on the way).  The norm backward
-# kernel can write that cast next to the fp32 rows, which saves a pass over them.  One slot: the producer leaves
-# (fp32 rows, bf16 copy) here, the next _residual_grad takes the copy if it is handed the very same buffer; holding the
-# fp32 tensor keeps its memory from being reused for anything else in between.
-_SHADOW: list = [None]
-_SHADOW_ON = os.environ.get("VITK_NO_SHADOW", "") == ""
+# kernel can write that cast next to the fp32 rows, which saves a pass over them.  The copy travels with the gradient
+# itself: the producing backward attaches it to the tensor it returns, and the consuming backward reads it from the very
+# tensor object autograd hands it.  If autograd had to build another tensor on the way (a gradient accumulated from two
+# consumers, a dtype conversion), the attribute is simply not there and the consumer casts as usual; an accumulation
+# done in place into the carrying tensor changes its version counter, which the consumer checks.
+_CARRY_BF16 = os.environ.get("VITK_NO_SHADOW", "") == ""
 
 
 def _shadow_buffer(dx: Tensor, tc: torch.dtype, rows: Optional[Tensor]) -> Optional[Tensor]:
-    if not _SHADOW_ON or rows is not None or dx.dtype != torch.float32 or tc != torch.bfloat16:
+    if not _CARRY_BF16 or rows is not None or dx.dtype != torch.float32 or tc != torch.bfloat16:
         return None
     return torch.empty(dx.shape, dtype=torch.bfloat16, device=dx.device)
 
 
-def _offer_shadow(dx: Tensor, shadow: Optional[Tensor]) -> None:
-    _SHADOW[0] = None if shadow is None else (dx, shadow)
+def _attach_bf16(dx: Tensor, shadow: Optional[Tensor]) -> Tensor:
+    """``dx`` is the gradient about to be returned to autograd; ``shadow`` holds the same values in bf16 (flattened rows)."""
+    if shadow is not None:
+        dx._vitk_bf16 = (shadow, dx._version)   # the version tells an in-place accumulation into dx apart
+    return dx
 
 
-def _take_shadow(dnew2: Tensor) -> Optional[Tensor]:
-    entry, _SHADOW[0] = _SHADOW[0], None
+def _carried_bf16(dnew: Tensor, D: int) -> Optional[Tensor]:
+    entry = getattr(dnew, "_vitk_bf16", None)
     if entry is None:
         return None
-    src, shadow = entry
-    same = (src.device == dnew2.device and src.data_ptr() == dnew2.data_ptr() and src.shape == dnew2.shape
-            and src.dtype == dnew2.dtype)
-    return shadow if same else None
+    shadow, version = entry
+    if (dnew._version != version or dnew.dtype != torch.float32 or not dnew.is_contiguous()
+            or shadow.numel() != dnew.numel() or shadow.device != dnew.device):
+        return None
+    return shadow.view(-1, D)
 
 
 def _residual_grad(dnew2: Tensor, tc: torch.dtype, gamma: Optional[Tensor], rows: Optional[Tensor], nrows: int, alpha: float,
-                   drop_p: float, seed: int, aux: Optional[Tensor], need_dgamma: bool):
-    """Gradient w.r.t. the linear's output, and w.r.t. gamma."""
+                   drop_p: float, seed: int, aux: Optional[Tensor], need_dgamma: bool, shadow: Optional[Tensor] = None):
+    """Gradient w.r.t. the linear's output, and w.r.t. gamma.  ``shadow``: dnew2 in bf16 if the producer supplied it."""
     N = dnew2.shape[1]
-    shadow = _take_shadow(dnew2)
     if shadow is not None and gamma is None and rows is None and alpha == 1.0 and drop_p == 0.0 and tc == torch.bfloat16:
         return shadow, None
     if gamma is None and rows is None and alpha == 1.0 and drop_p == 0.0 and dnew2.dtype == tc:
@@ -287,7 +333,7 @@ class AttentionSublayerFn(torch.autograd.Function):
 
         xn, rstd, mean = K.norm_fwd(x2, norm_w.detach(), None if norm_b is None else norm_b.detach(), opt["eps"],
                                     opt["layernorm"], tc, rows)
-        wq, bq, wo, bo = _cast(w_qkv, tc), _cast(b_qkv, tc), _cast(w_out, tc), _cast(b_out, tc)
+        wq, bq, wo, bo = _cast_param(w_qkv, tc), _cast_param(b_qkv, tc), _cast_param(w_out, tc), _cast_param(b_out, tc)
         qkv = torch.empty((M, 3 * D), dtype=tc, device=x.device)
         K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv")
         # per-head q/k normalisation over Dh, before RoPE (vit/attention.py:25-41, :95-105).  The heads of q (and of k)
@@ -319,6 +365,7 @@ class AttentionSublayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows, qn_w, kn_w, *qk_saved)
         ctx.meta = (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, x.dtype, w_qkv.dtype,
                     norm_b is not None, b_qkv is not None, b_out is not None, qn_b is not None, kn_b is not None)
+        ctx.ptrs = _ptrs(w_qkv, b_qkv, w_out, b_out)
         return y
 
     @staticmethod
@@ -328,12 +375,13 @@ class AttentionSublayerFn(torch.autograd.Function):
         (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, xdtype, wdtype, has_nb, has_bq,
          has_bo, has_qnb, has_knb) = ctx.meta
         need = ctx.needs_input_grad
+        ptrs = ctx.ptrs
         M = Bk * S
         residual = opt["residual"]
         dnew2 = _cast(dnew.reshape(-1, D), tr)
         dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
-                                    opt["alpha"] if residual else 1.0, p_hid, seed_h, aux, need[7])
-        do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[5], has_bo and need[6], wdtype, tag="out")
+                                    opt["alpha"] if residual else 1.0, p_hid, seed_h, aux, need[7], _carried_bf16(dnew, D))
+        do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[5], has_bo and need[6], wdtype, tag="out", w_ptr=ptrs[2], b_ptr=ptrs[3])
         dqkv = K.attn_bwd(qkv, o, lse, do, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
         if table is not None:
             K.rope_qk_(dqkv, table, Bk, S, H, Dh, S - table.shape[-2], True, emu)
@@ -347,7 +395,7 @@ class AttentionSublayerFn(torch.autograd.Function):
                                       has_b and need[11 + 2 * which])
                 dqkv[:, which * D:(which + 1) * D].copy_(dpre.view(M, D))
                 dqn[2 * which], dqn[2 * which + 1] = dw_, db_
-        dxn, dwq, dbq = _linear_bwd(dqkv, xn, wq, True, need[3], has_bq and need[4], wdtype, tag="qkv")
+        dxn, dwq, dbq = _linear_bwd(dqkv, xn, wq, True, need[3], has_bq and need[4], wdtype, tag="qkv", w_ptr=ptrs[0], b_ptr=ptrs[1])
         if residual:
             if rows is None:
                 dx = torch.empty_like(dnew2)
@@ -361,10 +409,11 @@ class AttentionSublayerFn(torch.autograd.Function):
         shadow = _shadow_buffer(dx, tc, rows) if residual else None
         dnw, dnb = K.norm_bwd(dxn, x2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dx, need[1], has_nb and need[2], rows,
                               dx_bf16=shadow)
-        _offer_shadow(dx, shadow)
         dx = dx.view(B, S, D)
         if dx.dtype != xdtype:
             dx = dx.to(xdtype)
+        else:
+            _attach_bf16(dx, shadow)
         if dgamma is not None and dgamma.dtype != g.dtype:
             dgamma = dgamma.to(g.dtype)
         return (dx if need[0] else None, dnw, dnb, dwq, dbq, dwo, dbo, dgamma, None, None, *dqn, None)
@@ -515,7 +564,7 @@ def self_attention_weights(x, norm_w, norm_b, w_qkv, b_qkv, qn_w, qn_b, kn_w, kn
     M = B * S
     xn, _, _ = K.norm_fwd(x.reshape(M, D).contiguous(), norm_w, norm_b, opt["eps"], opt["layernorm"], tc)
     qkv = torch.empty((M, 3 * D), dtype=tc, device=x.device)
-    K.gemm(xn, _cast(w_qkv, tc), trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=_cast(b_qkv, tc))
+    K.gemm(xn, _cast_param(w_qkv, tc), trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=_cast_param(b_qkv, tc))
     if qn_w is not None:
         for which, (w_, b_) in enumerate(((qn_w, qn_b), (kn_w, kn_b))):
             pre = qkv[:, which * D:(which + 1) * D].contiguous().view(M * H, Dh)
@@ -539,10 +588,10 @@ def cross_attention_weights(q, kv, norm_w, norm_b, w_q, b_q, w_kv, b_kv, qn_w, q
     Mq, Mk = B * Lq, B * Lk
     qn, _, _ = K.norm_fwd(q.reshape(Mq, D).contiguous(), norm_w, norm_b, opt["eps"], opt["layernorm"], tc)
     qp = torch.empty((Mq, D), dtype=tc, device=q.device)
-    K.gemm(qn, _cast(w_q, tc), trans_a=False, trans_b=False, M=Mq, N=D, K=D, out=qp, bias=_cast(b_q, tc))
+    K.gemm(qn, _cast_param(w_q, tc), trans_a=False, trans_b=False, M=Mq, N=D, K=D, out=qp, bias=_cast_param(b_q, tc))
     kvp = torch.empty((Mk, 2 * D), dtype=tc, device=q.device)
-    K.gemm(_cast(kv.reshape(Mk, D), tc), _cast(w_kv, tc), trans_a=False, trans_b=False, M=Mk, N=2 * D, K=D, out=kvp,
-           bias=_cast(b_kv, tc))
+    K.gemm(_cast(kv.reshape(Mk, D), tc), _cast_param(w_kv, tc), trans_a=False, trans_b=False, M=Mk, N=2 * D, K=D, out=kvp,
+           bias=_cast_param(b_kv, tc))
     if qn_w is not None:
         qp = K.norm_fwd(qp.view(Mq * H, Dh), qn_w, qn_b, opt["qk_eps"], opt["qk_layernorm"], tc)[0].view(Mq, D)
         nk = K.norm_fwd(kvp[:, :D].contiguous().view(Mk * H, Dh), kn_w, kn_b, opt["qk_eps"], opt["qk_layernorm"], tc)[0]
@@ -615,7 +664,7 @@ class MlpSublayerFn(torch.autograd.Function):
                                         opt["layernorm"], tc, rows)
         else:
             xn, rstd, mean = _cast(x2 if rows is None else x2.index_select(0, rows), tc), None, None
-        w1c, b1c, w2c, b2c = _cast(w1, tc), _cast(b1, tc), _cast(w2, tc), _cast(b2, tc)
+        w1c, b1c, w2c, b2c = _cast_param(w1, tc), _cast_param(b1, tc), _cast_param(w2, tc), _cast_param(b2, tc)
         p = torch.empty((M, F1), dtype=tc, device=x.device)
         seed_1 = next_seed(x.device) if p_hid > 0 else 0
         fused = K.can_fuse_activation(tc, D, F)
@@ -639,6 +688,7 @@ class MlpSublayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, norm_w, rstd, mean, xn, p, h, w1c, w2c, g, aux, rows)
         ctx.meta = (shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, x.dtype, w1.dtype, norm_b is not None, b1 is not None,
                     b2 is not None, fused)
+        ctx.ptrs = _ptrs(w1, b1, w2, b2)
         return y
 
     @staticmethod
@@ -646,21 +696,24 @@ class MlpSublayerFn(torch.autograd.Function):
         x2, norm_w, rstd, mean, xn, p, h, w1c, w2c, g, aux, rows = ctx.saved_tensors
         shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, xdtype, wdtype, has_nb, has_b1, has_b2, fused = ctx.meta
         need = ctx.needs_input_grad
+        ptrs = ctx.ptrs
         M = xn.shape[0]
         residual = opt["residual"]
         dnew2 = _cast(dnew.reshape(-1, D), tr)
         dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
-                                    opt["alpha"] if residual else 1.0, p_hid, seed_2, aux, need[7])
+                                    opt["alpha"] if residual else 1.0, p_hid, seed_2, aux, need[7], _carried_bf16(dnew, D))
         if fused:  # fc2 dgrad with the activation backward in its epilogue: dh never reaches memory
-            _, dw2, db2 = _linear_bwd(dy, h, w2c, False, need[5], has_b2 and need[6], wdtype, tag="fc2")
+            _, dw2, db2 = _linear_bwd(dy, h, w2c, False, need[5], has_b2 and need[6], wdtype, tag="fc2", w_ptr=ptrs[2],
+                                      b_ptr=ptrs[3])
             dp = torch.empty_like(p)
             K.gemm(dy, w2c, trans_a=False, trans_b=True, M=M, N=F, K=D, out=dp, aux=p,
                    epilogue=L.EPI_DGLU if opt["glu"] else L.EPI_DACT, act=opt["act"], limit=opt["limit"],
                    extra=opt["extra_bias"], drop_p=p_hid, seed=seed_1, ldo=p.shape[1], tag="fc2.dgrad")
         else:
-            dh, dw2, db2 = _linear_bwd(dy, h, w2c, True, need[5], has_b2 and need[6], wdtype, tag="fc2")
+            dh, dw2, db2 = _linear_bwd(dy, h, w2c, True, need[5], has_b2 and need[6], wdtype, tag="fc2", w_ptr=ptrs[2],
+                                       b_ptr=ptrs[3])
             dp = K.act_bwd(dh, p, F, opt["glu"], opt["act"], opt["limit"], opt["extra_bias"], p_hid, seed_1)
-        dxn, dw1, db1 = _linear_bwd(dp, xn, w1c, True, need[3], has_b1 and need[4], wdtype, tag="fc1")
+        dxn, dw1, db1 = _linear_bwd(dp, xn, w1c, True, need[3], has_b1 and need[4], wdtype, tag="fc1", w_ptr=ptrs[0], b_ptr=ptrs[1])
         dnw = dnb = None
         if norm_w is not None:
             if residual:
@@ -675,14 +728,16 @@ class MlpSublayerFn(torch.autograd.Function):
             shadow = _shadow_buffer(dx, tc, rows) if residual else None
             dnw, dnb = K.norm_bwd(dxn, x2, norm_w.detach(), rstd, mean, opt["layernorm"], add, dx, need[1],
                                   has_nb and need[2], rows, dx_bf16=shadow)
-            _offer_shadow(dx, shadow)
         else:
+            shadow = None
             dx = dxn.to(x2.dtype)
             if residual:
                 dx = dx + dnew2 if rows is None else dnew2.index_add(0, rows, dx)
         dx = dx.view(shape)
         if dx.dtype != xdtype:
             dx = dx.to(xdtype)
+        else:
+            _attach_bf16(dx, shadow)
         if dgamma is not None and dgamma.dtype != g.dtype:
             dgamma = dgamma.to(g.dtype)
         return (dx if need[0] else None, dnw, dnb, dw1, db1, dw2, db2, dgamma, None, None)
@@ -693,10 +748,14 @@ class MlpSublayerFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class PatchEmbedFn(torch.autograd.Function):
     """``fold`` > 1: x holds ``fold`` depth slabs per sample as consecutive batch entries (3-D patches with the depth
-    offsets folded into the channels); the position table then covers fold * gh * gw tokens per sample."""
+    offsets folded into the channels); the position table then covers fold * gh * gw tokens per sample.
+
+    With ``cls_tokens`` / ``register_tokens`` ([1, n, D] each) the result is the whole input sequence of the blocks,
+    cat([cls, register, patches], dim=1) in the promoted dtype (vit/vit.py:500-505): the GEMM epilogue writes the patch
+    rows behind the prefix rows, one small kernel broadcasts the learned tokens, and no copy of the sequence is made."""
 
     @staticmethod
-    def forward(ctx, x, w, b, pos, fold):
+    def forward(ctx, x, w, b, pos, fold, cls_tokens, register_tokens):
         L.require_gpu(x, w)
         tc = compute_dtype(w.dtype)
         B, Cc, H, W = x.shape
@@ -706,39 +765,68 @@ class PatchEmbedFn(torch.autograd.Function):
         Kc = Cc * ph * pw
         Kp = (Kc + 63) // 64 * 64  # pad the contraction to the MFMA kernel's K-tile; padding columns are zero
         cols = K.im2col(x.detach(), ph, pw, Kp, tc)
-        wc = torch.zeros((D, Kp), dtype=tc, device=x.device)
-        wc[:, :Kc] = w.detach().reshape(D, Kc)
-        bc = _cast(b, tc)
+
+        def padded(wd: Tensor) -> Tensor:
+            wp = torch.zeros((D, Kp), dtype=tc, device=wd.device)
+            wp[:, :Kc] = wd.reshape(D, Kc)
+            return wp
+
+        wc = _cast_param(w, tc, make=padded)
+        bc = _cast_param(b, tc)
         posc = None if pos is None else _cast(pos.reshape(N * fold, D), tc)
-        y = torch.empty((B * N, D), dtype=tc, device=x.device)
+        Bs, T = B // fold, N * fold          # samples, patch tokens per sample
+        with_prefix = cls_tokens is not None
+        ncls = cls_tokens.shape[1] if with_prefix else 0
+        nreg = register_tokens.shape[1] if with_prefix else 0
+        npre = ncls + nreg
+        odt = tc
+        if with_prefix:
+            odt = torch.promote_types(torch.promote_types(cls_tokens.dtype, register_tokens.dtype), tc)
+        y = torch.empty((Bs, npre + T, D), dtype=odt, device=x.device)
         K.gemm(cols, wc, trans_a=False, trans_b=False, M=B * N, N=D, K=Kp, out=y, bias=bc, epilogue=L.EPI_PATCH, pos=posc,
-               tokens=N * fold, seq=N * fold, prefix=0)
+               tokens=T, seq=npre + T, prefix=npre)
+        if npre:
+            pdt = torch.promote_types(cls_tokens.dtype, register_tokens.dtype)
+            K.prefix_fill_(y, cls_tokens.detach().to(pdt), register_tokens.detach().to(pdt))
         ctx.save_for_backward(cols, wc)
         ctx.meta = (x.shape, w.shape, x.dtype, w.dtype, tc, N, Kc, Kp, b is not None, None if pos is None else (pos.shape, pos.dtype),
-                    fold)
-        return y.view(B // fold, N * fold, D)
+                    fold, ncls, nreg, None if not with_prefix else (cls_tokens.dtype, register_tokens.dtype))
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         cols, wc = ctx.saved_tensors
-        xshape, wshape, xdtype, wdtype, tc, N, Kc, Kp, has_b, posinfo, fold = ctx.meta
+        xshape, wshape, xdtype, wdtype, tc, N, Kc, Kp, has_b, posinfo, fold, ncls, nreg, pdts = ctx.meta
         need = ctx.needs_input_grad
         B = xshape[0]
         D = wshape[0]
-        dy2 = _cast(dy.reshape(B * N, D), tc)
-        dx = dw = db = dpos = None
+        Bs, T, npre = B // fold, N * fold, ncls + nreg
+        S = npre + T
+        dy = dy.contiguous()
+        if npre:   # the patch rows of every sample, gathered and cast in one pass
+            dy2 = K.scale_cast(dy.view(Bs, S * D)[:, npre * D:], Bs, T * D, tc, ldg=S * D).view(B * N, D)
+        else:
+            dy2 = _cast(dy.reshape(B * N, D), tc)
+        dx = dw = db = dpos = dcls = dreg = None
         dcols, dwp, db = _linear_bwd(dy2, cols, wc, need[0], need[1], has_b and need[2], wdtype)
         if dwp is not None:
             dw = dwp[:, :Kc].reshape(wshape).contiguous()
         if dcols is not None:
             dx = K.col2im(dcols, xshape, wshape[2], wshape[3], xdtype)
         if posinfo is not None and need[3]:
-            dpos = K.colsum(dy2, B // fold, N * fold * D, N * fold * D, posinfo[1]).view(posinfo[0])
-        return dx, dw, db, dpos, None
+            dpos = K.colsum(dy2, Bs, T * D, T * D, posinfo[1]).view(posinfo[0])
+        if npre:
+            flat = dy.view(Bs, S * D)
+            if need[5] and ncls:
+                dcls = K.colsum(flat, Bs, ncls * D, S * D, pdts[0]).view(1, ncls, D)
+            if need[6] and nreg:
+                dreg = K.colsum(flat[:, ncls * D:], Bs, nreg * D, S * D, pdts[1]).view(1, nreg, D)
+        return dx, dw, db, dpos, None, dcls, dreg
 
 
-def patch_embed(x: Tensor, weight: Tensor, bias: Optional[Tensor], pos: Optional[Tensor], fold: int = 1) -> Tensor:
-    return PatchEmbedFn.apply(x, weight, bias, pos, fold)
+def patch_embed(x: Tensor, weight: Tensor, bias: Optional[Tensor], pos: Optional[Tensor], fold: int = 1,
+                cls_tokens: Optional[Tensor] = None, register_tokens: Optional[Tensor] = None) -> Tensor:
+    return PatchEmbedFn.apply(x, weight, bias, pos, fold, cls_tokens, register_tokens)
 
 
 # ------------------------------------------------------------------------------------------------

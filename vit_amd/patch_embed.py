@@ -3,7 +3,7 @@ parameter holder (state_dict keys stem.patch.weight / .bias); the convolution ru
 with bias and the position table added in the GEMM epilogue."""
 from __future__ import annotations
 
-from typing import Sequence
+from typing import Optional, Sequence, Tuple
 
 import torch.nn as nn
 from torch import Tensor
@@ -36,9 +36,12 @@ class PatchEmbed2d(nn.Module):
     def original_size(self, size: Sequence[int]):
         return tuple(s * p for s, p in zip(size, self.patch_size))
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, prefix: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+        """``prefix`` = (cls_tokens, register_tokens): return the blocks' whole input sequence
+        cat([cls, register, patches], dim=1) (vit/vit.py:500-505) instead of the patch tokens alone."""
         pos = self.pos_enc(self.tokenized_size(x.shape[2:])) if self.pos_enc is not None else None
-        return ops.patch_embed(x, self.patch.weight, self.patch.bias, pos)
+        cls_tokens, register_tokens = prefix if prefix is not None else (None, None)
+        return ops.patch_embed(x, self.patch.weight, self.patch.bias, pos, 1, cls_tokens, register_tokens)
 
 
 class PatchEmbed3d(nn.Module):
@@ -68,7 +71,7 @@ class PatchEmbed3d(nn.Module):
     def original_size(self, size: Sequence[int]):
         return tuple(s * p for s, p in zip(size, self.patch_size))
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, prefix: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
         B, C, Dz, H, W = x.shape
         pd, ph, pw = self.patch_size
         gd = Dz // pd
@@ -76,4 +79,5 @@ class PatchEmbed3d(nn.Module):
         # [B, C, gd*pd, H, W] -> [B*gd, C*pd, H, W]: channel index c*pd + t, the order of the Conv3d weight's (c, t, u, v)
         slabs = x[:, :, : gd * pd].reshape(B, C, gd, pd, H, W).permute(0, 2, 1, 3, 4, 5).reshape(B * gd, C * pd, H, W)
         w = self.patch.weight.reshape(self.patch.weight.shape[0], C * pd, ph, pw)
-        return ops.patch_embed(slabs, w, self.patch.bias, pos, fold=gd)
+        cls_tokens, register_tokens = prefix if prefix is not None else (None, None)
+        return ops.patch_embed(slabs, w, self.patch.bias, pos, gd, cls_tokens, register_tokens)

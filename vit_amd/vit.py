@@ -151,11 +151,16 @@ class ViT(nn.Module):
                 output_norm: bool = True) -> ViTFeatures:
         c = self._config
         grid = self.stem.tokenized_size(x.shape[2:])
-        x = self.stem(x)
-        x = self.normalize_patch_embeddings(x)
-        if mask is not None:   # dropped tokens leave the sequence before the blocks (vit/vit.py:545)
-            x = apply_mask(mask, x)
-        x = self.add_prefix_tokens(x)
+        if mask is None and self.patch_embed_norm is None:
+            # nothing stands between the patch embedding and the concatenation: its GEMM writes the patch rows straight
+            # into the sequence, behind the prefix tokens
+            x = self.stem(x, prefix=(self.cls_tokens, self.register_tokens))
+        else:
+            x = self.stem(x)
+            x = self.normalize_patch_embeddings(x)
+            if mask is not None:   # dropped tokens leave the sequence before the blocks (vit/vit.py:545)
+                x = apply_mask(mask, x)
+            x = self.add_prefix_tokens(x)
         rope = self.prepare_rope(grid, mask, rope_seed) if self.rope is not None else None
         for block in self.blocks:
             assert isinstance(block, TransformerEncoderLayer)

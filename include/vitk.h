@@ -87,7 +87,7 @@ typedef struct VitkGemm {
   const void* gamma;     /* RESIDUAL: [N] dtype out_dtype, or NULL */
   const int64_t* row_idx;/* RESIDUAL: [M] or NULL */
   void* aux;             /* RESIDUAL: [M, N] dtype in_dtype, or NULL */
-  const void* pos;       /* PATCH: [tokens, N] dtype in_dtype, or NULL */
+  const void* pos;       /* PATCH: [tokens, N] dtype in_dtype (float32 if pos_f32), or NULL */
   void* workspace;
   int64_t workspace_bytes;
   int64_t M, N, K;
@@ -112,6 +112,10 @@ typedef struct VitkGemm {
                             256 bytes of the workspace and zeroed on `stream` by the call) instead of taking fixed shares;
                             for callers whose collectives run on another stream beside the GEMMs and hold CUs meanwhile
                             (vit_amd/ddp.py).  vitk_gemm_workspace_bytes accounts for the counters. */
+  int32_t pos_f32;       /* PATCH: 1 = pos holds float32 values whatever in_dtype is, and is added to the rounded tokens
+                            without a further rounding; out_dtype must be float32.  This is a learned position table
+                            under autocast: vit/pos_enc.py:79-90 returns the fp32 parameter, vit/patch_embed.py:57 adds
+                            it to the bf16 convolution output, and the promoted sum is fp32. */
 } VitkGemm;
 
 size_t vitk_gemm_workspace_bytes(const VitkGemm* g);

@@ -57,6 +57,12 @@ CASES["g14_patch3d_fourier_fp32"] = (dict(activation="swiglu", pos_enc="fourier"
                                           num_register_tokens=2), 2, (18, 32, 32), "fp32")
 CASES["g14_patch3d_learnable_autocast"] = (dict(activation="srelu", pos_enc="learnable", patch_size=(4, 8, 8), img_size=(16, 32, 32),
                                                 num_cls_tokens=1), 2, (16, 32, 32), "autocast_bf16")
+# learned 2-D position table under autocast: the fp32 table is added to the bf16 tokens and the sum stays fp32
+# (vit/pos_enc.py:79-90, vit/patch_embed.py:57)
+CASES["g15_learnable_autocast"] = (dict(activation="swiglu", pos_enc="learnable", num_cls_tokens=1, num_register_tokens=2), 2,
+                                   (32, 32), "autocast_bf16")
+CASES["g15_learnable_resized_autocast"] = (dict(activation="srelu", pos_enc="learnable", num_register_tokens=1), 2, (48, 40),
+                                           "autocast_bf16")
 MASKED = {k for k in CASES if k.startswith("g11_masked")}
 
 

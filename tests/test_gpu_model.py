@@ -49,7 +49,8 @@ def run_train(model, x, autocast, seed, loss="square_mean", mask=None):
 
 # g03 trains with dropout on the learnable position table (CPU RNG stream of the fixture cannot be replayed on
 # the GPU).
-TRAIN_SKIP = {"g03_layernorm_gelu_learnable_cls_fp32", "g14_patch3d_learnable_autocast"}
+TRAIN_SKIP = {"g03_layernorm_gelu_learnable_cls_fp32", "g14_patch3d_learnable_autocast", "g15_learnable_autocast",
+              "g15_learnable_resized_autocast"}
 # These draw the drop-path subset with torch.randperm on the CPU generator in the fixture; the GPU generator
 # draws a different permutation, so the train pass is compared against the oracle on the GPU instead.
 RANDPERM = {"g04_droppath_layerscale_fp32", "g11_masked_fourier_droppath_fp32", "g11_masked_rope_droppath_fp32"}
@@ -551,3 +552,15 @@ def test_sequence_written_by_patch_embedding_equals_concatenation(autocast):
     assert set(p1) == set(p2) and {"cls_tokens", "register_tokens", "stem.patch.weight"} <= set(p1)
     for k in p1:
         assert torch.equal(p1[k], p2[k]), k
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_learnable_position_train_matches_oracle(autocast):
+    """Training pass with the learned position table (dropout 0.1 on the table: a torch op on both sides, so the oracle
+    on the GPU draws the same mask from the same seed).  Under autocast the fp32 table is added to the bf16 tokens and
+    the sum stays fp32 (vit/pos_enc.py:79-90, vit/patch_embed.py:57); the table's gradient is the unrounded batch sum."""
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 48), depth=2, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="learnable",
+                    num_register_tokens=2, num_cls_tokens=1, dtype=torch.float32)
+    compare_with_oracle_on_gpu(cfg, 4, (32, 48), autocast, 2e-2 if autocast else 1e-4, grad_rtol=5e-2 if autocast else None,
+                               oracle_device="cuda")

@@ -35,7 +35,7 @@ class VitkGemm(C.Structure):
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32), ("algo", C.c_int32),
         ("act", C.c_int32), ("use_limit", C.c_int32), ("use_extra", C.c_int32), ("limit", C.c_float), ("extra_bias", C.c_float),
-        ("a_colsum", C.c_void_p), ("dynamic_tiles", C.c_int32),
+        ("a_colsum", C.c_void_p), ("dynamic_tiles", C.c_int32), ("pos_f32", C.c_int32),
     ]
 
 

@@ -342,35 +342,42 @@ __device__ __forceinline__ void stage_load(uint4 (&r)[NCH], const TileSrc<NCH>& 
 #pragma unroll
   for (int i = 0; i < NCH; i++) r[i] = buf_load16(t.rsrc, t.off[i] + base);
 }
-template <int DHP, int NT, int NCH, int STRIDE, bool SWZ>
+// chunk swizzle of a staged tile that is read both ways (see Strides): 16-byte chunk c of row r sits at chunk position
+// c ^ swz_of<1>(r); swz_of<0> leaves the chunks in place
+template <int SWZ>
+__device__ __forceinline__ int swz_of(int row) {
+  return SWZ == 1 ? (row >> 2) & 3 : 0;
+}
+
+template <int DHP, int NT, int NCH, int STRIDE, int SWZ>
 __device__ __forceinline__ void stage_store(const uint4 (&r)[NCH], char* s, int tid) {
   constexpr int CPR = DHP / 8;
 #pragma unroll
   for (int i = 0; i < NCH; i++) {
     const int c = tid + i * NT;
     const int row = c / CPR, dc = c % CPR;
-    const int pc = SWZ ? (dc ^ ((row >> 2) & 3)) : dc;
+    const int pc = dc ^ swz_of<SWZ>(row);
     if (c < 64 * CPR) *(uint4*)(s + row * STRIDE + pc * 16) = r[i];
   }
 }
 
 // row-wise operand fragment: element j = tile[r0 + (lane&31)][ks*16 + 8*(lane>>5) + j]   (r0 a multiple of 32)
-template <int STRIDE, bool SWZ>
+template <int STRIDE, int SWZ>
 __device__ __forceinline__ bf16x8 frag_rows(const char* s, int r0, int ks, int lane) {
   const int row = r0 + (lane & 31);
   int chunk = ks * 2 + (lane >> 5);
-  if (SWZ) chunk ^= (row >> 2) & 3;
+  chunk ^= swz_of<SWZ>(row);
   return *(const bf16x8*)(s + row * STRIDE + chunk * 16);
 }
 // column-wise operand fragment for a product whose other operand is an accumulator tile converted in
 // place: element j = tile[r0 + 16*s2 + 8*(j>>2) + 4*(lane>>5) + (j&3)][c0 + (lane&31)]
-template <int STRIDE, bool SWZ>
+template <int STRIDE, int SWZ>
 __device__ __forceinline__ bf16x8 frag_cols(const char* s, int r0, int s2, int c0, int lane) {
   const int row = r0 + 16 * s2 + 4 * (lane >> 5) + ((lane & 15) >> 2);
   const int col = c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const int chunk = col >> 3, sub = (col & 7) * 2;
-  const int c_lo = SWZ ? (chunk ^ ((row >> 2) & 3)) : chunk;
-  const int c_hi = SWZ ? (chunk ^ (((row + 8) >> 2) & 3)) : chunk;
+  const int c_lo = chunk ^ swz_of<SWZ>(row);
+  const int c_hi = chunk ^ swz_of<SWZ>(row + 8);
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + row * STRIDE + c_lo * 16 + sub));
   bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + (row + 8) * STRIDE + c_hi * 16 + sub));
   bf16x8 f;
@@ -443,12 +450,37 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 #define ZERO16 {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
 #define MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
 
+// Workgroup -> (batch, head, block of stationary rows) for the streaming kernels, from a 1-D grid.  Workgroups are dealt
+// to the 8 XCDs round-robin in launch order and every XCD has its own L2, so the blocks that share one head's streamed
+// operands are given launch ids 8 apart: they run on the same XCD at about the same time, and the operands come from
+// memory once per head instead of once per block.
+struct HeadBlock {
+  int64_t b, h;
+  int xb;
+  bool valid;
+};
+__device__ __forceinline__ HeadBlock head_block(const AttnP& p, int rows_per_block) {
+  const int nxb = (int)((p.S + rows_per_block - 1) / rows_per_block);
+  const int64_t per = 8 * (int64_t)nxb, L = blockIdx.x;
+  const int64_t g = L / per, r = L - g * per;
+  const int64_t hh = g * 8 + (r & 7);
+  HeadBlock o;
+  o.xb = (int)(r >> 3);
+  o.valid = hh < p.B * p.H;
+  o.b = hh / p.H;
+  o.h = hh - o.b * p.H;
+  return o;
+}
+static unsigned head_block_grid(int64_t B, int64_t H, int64_t S, int rows_per_block) {
+  return (unsigned)(ceil_div(B * H, 8) * 8 * ceil_div(S, rows_per_block));
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 // One 64-key tile (HALVES = 2) or its first 32 keys (HALVES = 1) against a wave's 32 queries.  Scores are kept
 // transposed, S^T[key][query], so a lane owns one query: row statistics need one exchange with the partner lane, and the
 // exponentiated tile is already laid out as the B operand of the P V product.  The row sum is taken by the matrix
 // unit (a ones operand), on the same bf16-rounded probabilities that multiply V.
-template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS>
+template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS, int KW = 0, int VW = 0>
 __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const char* sV, const bf16x8 (&qf)[DHP / 16],
                                          f32x16 (&oacc)[DHP / 32], f32x16& lacc, float& m, float c, int k0, int S,
                                          uint64_t rbase, int lane) {
@@ -457,9 +489,9 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
   f32x16 sacc[HALVES];
 #pragma unroll
   for (int st = 0; st < HALVES; st++) {
-    sacc[st] = MFMA(frag_rows<KS, false>(sK, st * 32, 0, lane), qf[0], zero, 0, 0, 0);
+    sacc[st] = MFMA(frag_rows<KS, KW>(sK, st * 32, 0, lane), qf[0], zero, 0, 0, 0);
 #pragma unroll
-    for (int ks = 1; ks < DHP / 16; ks++) sacc[st] = MFMA(frag_rows<KS, false>(sK, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
+    for (int ks = 1; ks < DHP / 16; ks++) sacc[st] = MFMA(frag_rows<KS, KW>(sK, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
   }
   if (PARTIAL) {   // keys at or beyond S (only in the last half of the last tile) get probability 0
 #pragma unroll
@@ -510,7 +542,7 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
       }
 #pragma unroll
       for (int dt = 0; dt < DHP / 32; dt++)
-        oacc[dt] = MFMA(frag_cols<VS, false>(sV, st * 32, s2, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
+        oacc[dt] = MFMA(frag_cols<VS, VW>(sV, st * 32, s2, dt * 32, lane), pf, oacc[dt], 0, 0, 0);
     }
 }
 
@@ -523,9 +555,11 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP
   constexpr int KS = Strides<DHP>::ROWS, VS = Strides<DHP>::COLS, TILE = 64 * KS + 64 * VS;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE];   // double buffer: one barrier per key tile
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
-  const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int qrow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
-  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;   // else this wave only helps staging
+  const HeadBlock hb = head_block(p, NW * 32);
+  if (!hb.valid) return;
+  const int64_t b = hb.b, h = hb.h;
+  const int qrow = hb.xb * (NW * 32) + wid * 32 + (lane & 31);
+  const bool wave_on = hb.xb * (NW * 32) + wid * 32 < S;   // else this wave only helps staging
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -595,7 +629,7 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint64_t st4 = __builtin_amdgcn_s_memtime();
   if (tid == 0) {
-    uint32_t* dbg = (uint32_t*)p.lse + (((int64_t)blockIdx.z * p.H + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+    uint32_t* dbg = (uint32_t*)p.lse + (int64_t)blockIdx.x * 8;
     dbg[0] = (uint32_t)st0; dbg[1] = (uint32_t)(st0 >> 32); dbg[2] = (uint32_t)(st1 - st0); dbg[3] = (uint32_t)(st2 - st1);
     dbg[4] = (uint32_t)(st3 - st2); dbg[5] = (uint32_t)(st4 - st3);
     dbg[6] = __builtin_amdgcn_s_getreg(63492); dbg[7] = __builtin_amdgcn_s_getreg(6164);
@@ -604,7 +638,7 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP
 }
 
 // ---- backward: dQ -------------------------------------------------------------------------------
-template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS>
+template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS, int KW = 1, int VW = 0>
 __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const char* sV, const bf16x8 (&qf)[DHP / 16],
                                         const bf16x8 (&gf)[DHP / 16], f32x16 (&dqacc)[DHP / 32], float nlse2, float delta,
                                         float c, int k0, int S, uint64_t rbase, int lane) {
@@ -612,12 +646,12 @@ __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const ch
   const int rowoff = 4 * (lane >> 5);
 #pragma unroll
   for (int st = 0; st < HALVES; st++) {
-    f32x16 sacc = MFMA(frag_rows<KS, true>(sK, st * 32, 0, lane), qf[0], zero, 0, 0, 0);
-    f32x16 pacc = MFMA(frag_rows<VS, false>(sV, st * 32, 0, lane), gf[0], zero, 0, 0, 0);
+    f32x16 sacc = MFMA(frag_rows<KS, KW>(sK, st * 32, 0, lane), qf[0], zero, 0, 0, 0);
+    f32x16 pacc = MFMA(frag_rows<VS, VW>(sV, st * 32, 0, lane), gf[0], zero, 0, 0, 0);
 #pragma unroll
     for (int ks = 1; ks < DHP / 16; ks++) {
-      sacc = MFMA(frag_rows<KS, true>(sK, st * 32, ks, lane), qf[ks], sacc, 0, 0, 0);
-      pacc = MFMA(frag_rows<VS, false>(sV, st * 32, ks, lane), gf[ks], pacc, 0, 0, 0);
+      sacc = MFMA(frag_rows<KS, KW>(sK, st * 32, ks, lane), qf[ks], sacc, 0, 0, 0);
+      pacc = MFMA(frag_rows<VS, VW>(sV, st * 32, ks, lane), gf[ks], pacc, 0, 0, 0);
     }
     // dS^T[key][q] = P (dP - delta); keys beyond S contribute nothing
 #pragma unroll
@@ -634,7 +668,7 @@ __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const ch
       const bf16x8 df = acc_to_frag(sacc, s2);
 #pragma unroll
       for (int dt = 0; dt < DHP / 32; dt++)
-        dqacc[dt] = MFMA(frag_cols<KS, true>(sK, st * 32, s2, dt * 32, lane), df, dqacc[dt], 0, 0, 0);
+        dqacc[dt] = MFMA(frag_cols<KS, KW>(sK, st * 32, s2, dt * 32, lane), df, dqacc[dt], 0, 0, 0);
     }
   }
 }
@@ -646,10 +680,12 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP 
   constexpr int TILE = 64 * KS + 64 * VS;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
-  const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int qrow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
+  const HeadBlock hb = head_block(p, NW * 32);
+  if (!hb.valid) return;
+  const int64_t b = hb.b, h = hb.h;
+  const int qrow = hb.xb * (NW * 32) + wid * 32 + (lane & 31);
   const bool qv = qrow < S;
-  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;
+  const bool wave_on = hb.xb * (NW * 32) + wid * 32 < S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -718,7 +754,7 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP 
 
 // ---- backward: dK, dV ---------------------------------------------------------------------------
 // Query rows at or beyond S carry -lse = -inf, so their probability (and with it dS) is exactly 0.
-template <int DHP, int HALVES, bool DROP, int QS>
+template <int DHP, int HALVES, bool DROP, int QS, int QW = 1>
 __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const char* sG, const float* sL,
                                           const bf16x8 (&kf)[DHP / 16], const bf16x8 (&vf)[DHP / 16],
                                           f32x16 (&dkacc)[DHP / 32], f32x16 (&dvacc)[DHP / 32], float c, int q0,
@@ -728,12 +764,12 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
 #pragma unroll
   for (int st = 0; st < HALVES; st++) {
     // sacc[r] = S[q = q0 + st*32 + row(r)][key = lane&31], pacc likewise for dP
-    f32x16 sacc = MFMA(frag_rows<QS, true>(sQ, st * 32, 0, lane), kf[0], zero, 0, 0, 0);
-    f32x16 pacc = MFMA(frag_rows<QS, true>(sG, st * 32, 0, lane), vf[0], zero, 0, 0, 0);
+    f32x16 sacc = MFMA(frag_rows<QS, QW>(sQ, st * 32, 0, lane), kf[0], zero, 0, 0, 0);
+    f32x16 pacc = MFMA(frag_rows<QS, QW>(sG, st * 32, 0, lane), vf[0], zero, 0, 0, 0);
 #pragma unroll
     for (int ks = 1; ks < DHP / 16; ks++) {
-      sacc = MFMA(frag_rows<QS, true>(sQ, st * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
-      pacc = MFMA(frag_rows<QS, true>(sG, st * 32, ks, lane), vf[ks], pacc, 0, 0, 0);
+      sacc = MFMA(frag_rows<QS, QW>(sQ, st * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
+      pacc = MFMA(frag_rows<QS, QW>(sG, st * 32, ks, lane), vf[ks], pacc, 0, 0, 0);
     }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -760,8 +796,8 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
       const bf16x8 df = acc_to_frag(pacc, s2);
 #pragma unroll
       for (int dt = 0; dt < DHP / 32; dt++) {
-        dvacc[dt] = MFMA(frag_cols<QS, true>(sG, st * 32, s2, dt * 32, lane), pf, dvacc[dt], 0, 0, 0);
-        dkacc[dt] = MFMA(frag_cols<QS, true>(sQ, st * 32, s2, dt * 32, lane), df, dkacc[dt], 0, 0, 0);
+        dvacc[dt] = MFMA(frag_cols<QS, QW>(sG, st * 32, s2, dt * 32, lane), pf, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = MFMA(frag_cols<QS, QW>(sQ, st * 32, s2, dt * 32, lane), df, dkacc[dt], 0, 0, 0);
       }
     }
   }
@@ -774,9 +810,11 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_
   constexpr int TILE = 2 * 64 * QS + 512;  // Q, dO, then -lse*log2e [64] and delta [64]
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
-  const int64_t b = blockIdx.z, h = blockIdx.y;
-  const int krow = (int)blockIdx.x * (NW * 32) + wid * 32 + (lane & 31);
-  const bool wave_on = (int)blockIdx.x * (NW * 32) + wid * 32 < S;
+  const HeadBlock hb = head_block(p, NW * 32);
+  if (!hb.valid) return;
+  const int64_t b = hb.b, h = hb.h;
+  const int krow = hb.xb * (NW * 32) + wid * 32 + (lane & 31);
+  const bool wave_on = hb.xb * (NW * 32) + wid * 32 < S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
   const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
   const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
@@ -846,6 +884,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_
   store_rows<DHP>((bf16*)p.dk + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dkacc, p.scale, Dh, lane);
   store_rows<DHP>((bf16*)p.dv + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dvacc, 1.f, Dh, lane);
 }
+
 #undef MFMA
 
 // ------------------------------------------------------------------------------------------------
@@ -936,7 +975,7 @@ extern "C" int vitk_attn_fwd(const VitkAttn* a, void* stream) {
   VITK_REQUIRE(a->algo != 2 || can, "attn_fwd: MFMA kernel cannot take this problem (dtype/alignment/head_dim)");
   if (can && a->algo != 1) {
     const int nw = pick_nw(a->S, a->Dh, true);
-    dim3 grid((unsigned)ceil_div(a->S, nw * 32), (unsigned)a->H, (unsigned)a->B);
+    dim3 grid(head_block_grid(a->B, a->H, a->S, nw * 32));
     ATTN_DISPATCH_DH(attn_fwd_k, a->Dh, nw, grid, p, st);
   } else {
     dim3 grid((unsigned)ceil_div(a->S, 64), (unsigned)a->H, (unsigned)a->B);
@@ -958,7 +997,7 @@ extern "C" int vitk_attn_bwd(const VitkAttn* a, void* stream) {
   VITK_REQUIRE(a->algo != 2 || can, "attn_bwd: MFMA kernel cannot take this problem (dtype/alignment/head_dim)");
   if (can && a->algo != 1) {
     const int nw = pick_nw(a->S, a->Dh, false);
-    dim3 grid((unsigned)ceil_div(a->S, nw * 32), (unsigned)a->H, (unsigned)a->B);
+    dim3 grid(head_block_grid(a->B, a->H, a->S, nw * 32));
     ATTN_DISPATCH_DH(attn_dq_k, a->Dh, nw, grid, p, st);    // also writes delta
     ATTN_DISPATCH_DH(attn_dkdv_k, a->Dh, nw, grid, p, st);  // reads delta
   } else {

@@ -661,6 +661,7 @@ static Epi make_epi(const VitkGemm* g) {
   e.keep_scale = 1.f / (1.f - g->drop_p);
   e.act = g->act; e.use_limit = g->use_limit; e.use_extra = g->use_extra; e.limit = g->limit; e.extra = g->extra_bias;
   e.asum = g->a_colsum; e.asum_partial = nullptr; e.m_off = 0;
+  e.pos_f32 = g->pos_f32 || g->in_dtype == VITK_F32;
   return e;
 }
 
@@ -842,6 +843,7 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   if (g->epilogue == VITK_EPI_PATCH)
     VITK_REQUIRE(g->tokens > 0 && g->M % g->tokens == 0 && g->seq >= g->prefix + g->tokens,
                  "gemm: PATCH epilogue needs tokens | M and seq >= prefix + tokens");
+  if (g->pos_f32) VITK_REQUIRE(g->epilogue == VITK_EPI_PATCH && g->out_dtype == VITK_F32, "gemm: pos_f32 needs the PATCH epilogue and a float32 output");
   if (g->a_colsum) VITK_REQUIRE(g->trans_a && g->epilogue == VITK_EPI_STORE, "gemm: a_colsum needs trans_a = 1 and the STORE epilogue");
   if (g->M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;

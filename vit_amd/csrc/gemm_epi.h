@@ -20,6 +20,7 @@ struct Epi {
   void* asum;            // A^T-layout products: asum[m] = sum over k of A[k, m] (dtype of out), or NULL
   float* asum_partial;   // split-K: per-split partial sums [splits][M]
   int64_t m_off;         // row of the whole problem that this launch's row 0 is (dropout stream index)
+  int pos_f32;           // PATCH: the position table holds fp32 values and is added without rounding (output fp32)
 };
 
 // sum of a fragment's 8 bf16 values added to s (4 x v_dot2c_f32_bf16 against ones)
@@ -95,7 +96,10 @@ struct EpiVec {
       p.row = e.row_idx ? e.row_idx[m] : m;
       p.r.load((const TO*)e.res + p.row * e.ldo + n);
     } else if (MODE == VITK_EPI_PATCH) {
-      if (e.pos) p.a.load((const TI*)e.pos + (m % e.tokens) * e.N + n);
+      if (e.pos) {
+        if (e.pos_f32) p.r.load((const TO*)e.pos + (m % e.tokens) * e.N + n);   // output type is float then
+        else p.a.load((const TI*)e.pos + (m % e.tokens) * e.N + n);
+      }
     } else if (MODE == EPI_DACT) {
       p.a.load((const TI*)e.aux + m * e.N + n);
     } else if (MODE == EPI_DGLU) {
@@ -143,7 +147,7 @@ struct EpiVec {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         o.v[j] = round_as<TI>(v[j]);
-        if (e.pos) o.v[j] = round_as<TI>(o.v[j] + p.a.get(j));
+        if (e.pos) o.v[j] = e.pos_f32 ? o.v[j] + p.r.get(j) : round_as<TI>(o.v[j] + p.a.get(j));
       }
       o.store((TO*)e.out + (b * e.seq + e.prefix + t) * e.ldo + n);
     } else if (MODE == EPI_ACT) {
@@ -260,7 +264,7 @@ struct EpiOp {
     } else {  // PATCH
       const int64_t b = m / e.tokens, t = m % e.tokens;
       v = round_as<TI>(v);
-      if (e.pos) v = round_as<TI>(v + to_f<TI>(((const TI*)e.pos)[t * e.N + n]));
+      if (e.pos) v = e.pos_f32 ? v + ((const float*)e.pos)[t * e.N + n] : round_as<TI>(v + to_f<TI>(((const TI*)e.pos)[t * e.N + n]));
       ((TO*)e.out)[(b * e.seq + e.prefix + t) * e.ldo + n] = from_f<TO>(v);
     }
   }

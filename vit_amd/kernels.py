@@ -116,8 +116,11 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     L.require_gpu(a, b, out, bias, res, gamma, aux, pos, a_colsum)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1, "gemm operands must be row-major 2-D"
     assert a.dtype == b.dtype
-    for t in (bias, aux, pos):
+    for t in (bias, aux):
         assert t is None or (t.dtype == a.dtype and t.is_contiguous())
+    # a position table wider than the operands (a learned fp32 table under autocast) is added unrounded to an fp32 output
+    pos_f32 = pos is not None and pos.dtype == torch.float32 and a.dtype != torch.float32
+    assert pos is None or (pos.is_contiguous() and (pos.dtype == a.dtype or (pos_f32 and out.dtype == torch.float32)))
     for t in (res, gamma):
         assert t is None or (t.dtype == out.dtype and t.is_contiguous())
     assert out.is_contiguous()
@@ -139,6 +142,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     g.epilogue = epilogue
     g.algo = _ALGO if algo is None else algo
     g.dynamic_tiles = int(_DYNAMIC_TILES)
+    g.pos_f32 = int(pos_f32)
     g.workspace, g.workspace_bytes = None, 0
     need = lib.vitk_gemm_workspace_bytes(C.byref(g))
     if need:

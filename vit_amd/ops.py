@@ -773,15 +773,18 @@ class PatchEmbedFn(torch.autograd.Function):
 
         wc = _cast_param(w, tc, make=padded)
         bc = _cast_param(b, tc)
-        posc = None if pos is None else _cast(pos.reshape(N * fold, D), tc)
+        # "y + pos" (vit/patch_embed.py:57): a table computed under autocast arrives in the compute dtype and the sum is
+        # rounded to it; a wider table (the learned fp32 parameter under autocast) promotes the sum to its dtype
+        pos_wide = pos is not None and torch.promote_types(pos.dtype, tc) != tc
+        posc = None if pos is None else _cast(pos.reshape(N * fold, D), pos.dtype if pos_wide else tc)
         Bs, T = B // fold, N * fold          # samples, patch tokens per sample
         with_prefix = cls_tokens is not None
         ncls = cls_tokens.shape[1] if with_prefix else 0
         nreg = register_tokens.shape[1] if with_prefix else 0
         npre = ncls + nreg
-        odt = tc
+        odt = posc.dtype if pos_wide else tc
         if with_prefix:
-            odt = torch.promote_types(torch.promote_types(cls_tokens.dtype, register_tokens.dtype), tc)
+            odt = torch.promote_types(torch.promote_types(cls_tokens.dtype, register_tokens.dtype), odt)
         y = torch.empty((Bs, npre + T, D), dtype=odt, device=x.device)
         K.gemm(cols, wc, trans_a=False, trans_b=False, M=B * N, N=D, K=Kp, out=y, bias=bc, epilogue=L.EPI_PATCH, pos=posc,
                tokens=T, seq=npre + T, prefix=npre)
@@ -790,13 +793,13 @@ class PatchEmbedFn(torch.autograd.Function):
             K.prefix_fill_(y, cls_tokens.detach().to(pdt), register_tokens.detach().to(pdt))
         ctx.save_for_backward(cols, wc)
         ctx.meta = (x.shape, w.shape, x.dtype, w.dtype, tc, N, Kc, Kp, b is not None, None if pos is None else (pos.shape, pos.dtype),
-                    fold, ncls, nreg, None if not with_prefix else (cls_tokens.dtype, register_tokens.dtype))
+                    fold, ncls, nreg, None if not with_prefix else (cls_tokens.dtype, register_tokens.dtype), pos_wide)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         cols, wc = ctx.saved_tensors
-        xshape, wshape, xdtype, wdtype, tc, N, Kc, Kp, has_b, posinfo, fold, ncls, nreg, pdts = ctx.meta
+        xshape, wshape, xdtype, wdtype, tc, N, Kc, Kp, has_b, posinfo, fold, ncls, nreg, pdts, pos_wide = ctx.meta
         need = ctx.needs_input_grad
         B = xshape[0]
         D = wshape[0]
@@ -814,7 +817,10 @@ class PatchEmbedFn(torch.autograd.Function):
         if dcols is not None:
             dx = K.col2im(dcols, xshape, wshape[2], wshape[3], xdtype)
         if posinfo is not None and need[3]:
-            dpos = K.colsum(dy2, Bs, T * D, T * D, posinfo[1]).view(posinfo[0])
+            if pos_wide:   # the table entered the sum in the output's dtype: its gradient is the unrounded batch sum
+                dpos = K.colsum(dy.view(Bs, S * D)[:, npre * D:], Bs, T * D, S * D, posinfo[1]).view(posinfo[0])
+            else:
+                dpos = K.colsum(dy2, Bs, T * D, T * D, posinfo[1]).view(posinfo[0])
         if npre:
             flat = dy.view(Bs, S * D)
             if need[5] and ncls:

@@ -75,7 +75,14 @@ enum {
    *   DACT (fc2 dgrad)     out[m,n] = dropmask * acc * act'(aux[m,n])
    *   DGLU (fc2 dgrad)     N = F, aux = pre-activations [M,2F]: out[m,f] = d lin, out[m,F+f] = d gate, out is [M,2F]
    * dropout index = m*F + f as in vitk_act_fwd/bwd, so fused and unfused paths draw the same mask. */
-  VITK_EPI_ACT = 3, VITK_EPI_GLU = 4, VITK_EPI_DACT = 5, VITK_EPI_DGLU = 6
+  VITK_EPI_ACT = 3, VITK_EPI_GLU = 4, VITK_EPI_DACT = 5, VITK_EPI_DGLU = 6,
+  /* ROPE (the fused QKV projection of vit/attention.py:93 followed by apply_rope on q and k, vit/rope.py:148-163, for
+   * head_dim 64; MFMA kernel only, bf16 operands and output, trans_a = trans_b = 0):
+   *   x = round(acc + bias);  rows whose index inside their sample (m % seq) is below `prefix`, and columns from
+   *   2 * rope_width on (the v section), are stored as they are; elsewhere, with t = m % seq - prefix and d = n % 64,
+   *   out[m,n] = x[m,n] cos[t,d] - x[m,n+32] sin[t,d]  (d < 32),   x[m,n] cos[t,d] + x[m,n-32] sin[t,d]  (d >= 32)
+   *   -- bit-identical to VITK_EPI_STORE followed by vitk_rope_qk with the same table. */
+  VITK_EPI_ROPE = 7
 };
 
 typedef struct VitkGemm {
@@ -92,7 +99,7 @@ typedef struct VitkGemm {
   int64_t workspace_bytes;
   int64_t M, N, K;
   int64_t lda, ldb, ldo;
-  int64_t tokens, seq, prefix; /* PATCH */
+  int64_t tokens, seq, prefix; /* PATCH; ROPE: seq = rows per sample, prefix = leading rows of a sample left unrotated */
   uint64_t seed;         /* dropout stream */
   float alpha;
   float drop_p;
@@ -116,6 +123,9 @@ typedef struct VitkGemm {
                             without a further rounding; out_dtype must be float32.  This is a learned position table
                             under autocast: vit/pos_enc.py:79-90 returns the fp32 parameter, vit/patch_embed.py:57 adds
                             it to the bf16 convolution output, and the promoted sum is fp32. */
+  const float* rope;     /* ROPE: [2, seq - prefix, 64] float32, sin then cos (one table for all samples) */
+  int64_t rope_width;    /* ROPE: columns per section, a multiple of 64 (N = 3 * rope_width for the packed q | k | v) */
+  int32_t rope_emulate_bf16; /* ROPE: as in vitk_rope_qk */
 } VitkGemm;
 
 size_t vitk_gemm_workspace_bytes(const VitkGemm* g);
@@ -146,6 +156,12 @@ typedef struct VitkAttn {
   int64_t Sk;                   /* 0 = self-attention */
   int64_t kv_sb, kv_sh, kv_ss;     /* strides of k/v when Sk > 0 */
   int64_t dkv_sb, dkv_sh, dkv_ss;  /* strides of dk/dv when Sk > 0 */
+  /* vitk_attn_bwd only, MFMA kernels with head_dim 64: q and k were rotated (apply_rope, vit/rope.py:148-163) before the
+   * attention, so dq and dk leave through the transposed rotation -- bit-identical to vitk_rope_qk(inverse = 1) on the
+   * dq / dk this call would otherwise store.  rope = NULL: no rotation. */
+  const float* rope;            /* [2, S - rope_prefix, 64] float32, sin then cos */
+  int64_t rope_prefix;          /* leading rows of every sample that were not rotated */
+  int32_t rope_emulate_bf16;    /* as in vitk_rope_qk */
 } VitkAttn;
 
 int vitk_attn_fwd(const VitkAttn* a, void* stream);

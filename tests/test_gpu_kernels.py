@@ -314,6 +314,56 @@ def test_rope_matches_half_split_rotation_and_inverse_is_transpose(dtype, emu):
     assert abs((Rx * y).sum().item() - (xf * RTy).sum().item()) < 1e-2 * abs((Rx * y).sum().item()) + 1e-2
 
 
+@pytest.mark.parametrize("emu", [False, True])
+@pytest.mark.parametrize("algo", [0, 3, 4, 5])
+@pytest.mark.parametrize("shape", [(3, 37, 2, 5), (9, 197, 6, 1), (256, 272, 12, 16)])
+def test_gemm_rope_epilogue_equals_projection_then_rotation(shape, algo, emu):
+    """VITK_EPI_ROPE (head_dim 64): the QKV projection with q and k rotated in its epilogue is bit-identical to the plain
+    projection followed by vitk_rope_qk; prefix rows and the v section pass through.  The largest shape is the ViT-B/14
+    step's own (a ragged last round: its rows are cut between the 256x256 and the 128x128 kernel)."""
+    B, S, H, prefix = shape
+    if B * S > 10000 and (algo != 0 or emu):
+        pytest.skip("the full-size shape runs once, on the automatic path")
+    Dh, D = 64, 64 * H
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * S, D, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(DEV, torch.bfloat16)
+    bias = torch.randn(3 * D, generator=g).to(DEV, torch.bfloat16)
+    ang = torch.rand(S - prefix, Dh, generator=g) * 6.28
+    table = torch.stack([ang.sin(), ang.cos()]).to(DEV)
+    if emu:
+        table = table.to(torch.bfloat16).float()
+    plain = torch.empty(B * S, 3 * D, device=DEV, dtype=torch.bfloat16)
+    K.gemm(x, w, trans_a=False, trans_b=False, M=B * S, N=3 * D, K=D, out=plain, bias=bias, algo=algo)
+    want = K.rope_qk_(plain.clone(), table, B, S, H, Dh, prefix, False, emu)
+    got = torch.empty_like(plain)
+    K.gemm(x, w, trans_a=False, trans_b=False, M=B * S, N=3 * D, K=D, out=got, bias=bias, algo=algo, epilogue=L.EPI_ROPE,
+           rope=table, rope_width=D, rope_emulate_bf16=emu, seq=S, prefix=prefix)
+    assert torch.equal(got, want)
+    assert not torch.equal(got, plain)
+
+
+@pytest.mark.parametrize("emu", [False, True])
+@pytest.mark.parametrize("S,prefix", [(64, 0), (197, 1), (272, 16), (600, 24)])
+def test_attention_backward_with_fused_inverse_rotation(S, prefix, emu):
+    """vitk_attn_bwd with a rope table (head_dim 64) is bit-identical to the plain backward followed by
+    vitk_rope_qk(inverse) on dq and dk; dv is untouched."""
+    B, H, Dh = 2, 3, 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B * S, 3 * H * Dh, generator=g).to(DEV, torch.bfloat16)
+    dout = torch.randn(B * S, H * Dh, generator=g).to(DEV, torch.bfloat16)
+    ang = torch.rand(S - prefix, Dh, generator=g) * 6.28
+    table = torch.stack([ang.sin(), ang.cos()]).to(DEV)
+    if emu:
+        table = table.to(torch.bfloat16).float()
+    o, lse = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, algo=2)
+    plain = K.attn_bwd(qkv, o, lse, dout, B, S, H, Dh, Dh ** -0.5, algo=2)
+    want = K.rope_qk_(plain.clone(), table, B, S, H, Dh, prefix, True, emu)
+    got = K.attn_bwd(qkv, o, lse, dout, B, S, H, Dh, Dh ** -0.5, algo=2, rope=table, rope_emulate_bf16=emu)
+    assert torch.equal(got, want)
+    assert not torch.equal(got, plain)
+
+
 ACTS = {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu,
         "srelu": lambda t: t.relu().pow(2), "openswiglu": lambda t: t * torch.sigmoid(1.702 * t)}
 

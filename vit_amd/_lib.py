@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(_HERE, "libvitk.so")   # VITK_LIB: an experimental build
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_RESIDUAL, EPI_PATCH, EPI_ACT, EPI_GLU, EPI_DACT, EPI_DGLU = 0, 1, 2, 3, 4, 5, 6
+EPI_STORE, EPI_RESIDUAL, EPI_PATCH, EPI_ACT, EPI_GLU, EPI_DACT, EPI_DGLU, EPI_ROPE = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_CODES = {"relu": 0, "reglu": 0, "silu": 1, "swiglu": 1, "gelu": 2, "geglu": 2, "srelu": 3, "openswiglu": 4}
 
 EXPORTS = [
@@ -36,6 +36,7 @@ class VitkGemm(C.Structure):
         ("epilogue", C.c_int32), ("algo", C.c_int32),
         ("act", C.c_int32), ("use_limit", C.c_int32), ("use_extra", C.c_int32), ("limit", C.c_float), ("extra_bias", C.c_float),
         ("a_colsum", C.c_void_p), ("dynamic_tiles", C.c_int32), ("pos_f32", C.c_int32),
+        ("rope", C.c_void_p), ("rope_width", C.c_int64), ("rope_emulate_bf16", C.c_int32),
     ]
 
 
@@ -52,6 +53,7 @@ class VitkAttn(C.Structure):
         ("dtype", C.c_int32), ("algo", C.c_int32),
         ("Sk", C.c_int64), ("kv_sb", C.c_int64), ("kv_sh", C.c_int64), ("kv_ss", C.c_int64),
         ("dkv_sb", C.c_int64), ("dkv_sh", C.c_int64), ("dkv_ss", C.c_int64),
+        ("rope", C.c_void_p), ("rope_prefix", C.c_int64), ("rope_emulate_bf16", C.c_int32),
     ]
 
 

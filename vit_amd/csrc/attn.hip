@@ -29,6 +29,8 @@ struct AttnP {
   uint64_t seed;
   float scale, keep_scale;
   uint32_t thr;
+  const float* rope;   // backward, head_dim 64: dq and dk leave through the transposed rotation (table [2, S - prefix, 64])
+  int rope_prefix, rope_emu;
 };
 
 #define LOG2E 1.4426950408889634f
@@ -445,6 +447,55 @@ __device__ __forceinline__ void store_rows(bf16* __restrict__ dst, const f32x16 
     }
 }
 
+// store_rows for head_dim 64 followed by the transpose of the rotation that was applied to the rows in forward
+// (vit/rope.py:148-163; the same arithmetic as vitk_rope_qk with inverse = 1 on the stored bf16 values):
+//   g[d] = y[d] cos[d] + y[d + 32] sin[d + 32]   (d < 32),   g[d] = y[d] cos[d] - y[d - 32] sin[d - 32]   (d >= 32)
+// with y the gradient rounded to bf16.  A lane holds d .. d + 7 of both halves of its row, so the partner is in
+// registers.  `tok` = the row's index behind the prefix; negative (a prefix row) stores y unrotated.
+__device__ __forceinline__ void store_rows_rope64(bf16* __restrict__ dst, const f32x16 (&acc)[2], float mul, int lane,
+                                                  const float* __restrict__ table, int tok, int ntok, int emu) {
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    uint32_t w[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) {
+      uint32_t a01 = pack_bf16(acc[dt][8 * h + 0] * mul, acc[dt][8 * h + 1] * mul);
+      uint32_t a23 = pack_bf16(acc[dt][8 * h + 2] * mul, acc[dt][8 * h + 3] * mul);
+      uint32_t b01 = pack_bf16(acc[dt][8 * h + 4] * mul, acc[dt][8 * h + 5] * mul);
+      uint32_t b23 = pack_bf16(acc[dt][8 * h + 6] * mul, acc[dt][8 * h + 7] * mul);
+      swap32(a01, b01);
+      swap32(a23, b23);
+      w[dt][0] = a01; w[dt][1] = a23; w[dt][2] = b01; w[dt][3] = b23;
+    }
+    const int d = 16 * h + 8 * (lane >> 5);   // first-half columns d .. d + 7, second-half columns d + 32 ..
+    if (tok >= 0) {
+      const float* sn = table + (int64_t)tok * 64 + d;
+      const float* cs = sn + (int64_t)ntok * 64;
+      float s1[8], s2[8], c1[8], c2[8];
+      *(float4*)s1 = *(const float4*)sn;        *(float4*)(s1 + 4) = *(const float4*)(sn + 4);
+      *(float4*)s2 = *(const float4*)(sn + 32); *(float4*)(s2 + 4) = *(const float4*)(sn + 36);
+      *(float4*)c1 = *(const float4*)cs;        *(float4*)(c1 + 4) = *(const float4*)(cs + 4);
+      *(float4*)c2 = *(const float4*)(cs + 32); *(float4*)(c2 + 4) = *(const float4*)(cs + 36);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float g1[2], g2[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; e2++) {
+          const int j = 2 * q + e2;
+          const float y1 = __builtin_bit_cast(float, e2 ? (w[0][q] & 0xffff0000u) : (w[0][q] << 16));
+          const float y2 = __builtin_bit_cast(float, e2 ? (w[1][q] & 0xffff0000u) : (w[1][q] << 16));
+          g1[e2] = rope_mix(y1, c1[j], y2, s2[j], emu);
+          g2[e2] = rope_mix(y2, c2[j], -y1, s1[j], emu);
+        }
+        w[0][q] = pack_bf16(g1[0], g1[1]);
+        w[1][q] = pack_bf16(g2[0], g2[1]);
+      }
+    }
+    *(uint4*)(dst + d) = make_uint4(w[0][0], w[0][1], w[0][2], w[0][3]);
+    *(uint4*)(dst + d + 32) = make_uint4(w[1][0], w[1][1], w[1][2], w[1][3]);
+  }
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // one v_exp_f32
 
 #define ZERO16 {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
@@ -749,7 +800,14 @@ __global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP 
     else dq_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, nfull * 64, S, rbase, lane);
   }
   if (!qv) return;
-  store_rows<DHP>((bf16*)p.dq + b * p.g_sb + h * p.g_sh + (int64_t)qrow * p.g_ss, dqacc, p.scale, Dh, lane);
+  bf16* dst = (bf16*)p.dq + b * p.g_sb + h * p.g_sh + (int64_t)qrow * p.g_ss;
+  if constexpr (DHP == 64) {
+    if (p.rope) {
+      store_rows_rope64(dst, dqacc, p.scale, lane, p.rope, qrow - p.rope_prefix, S - p.rope_prefix, p.rope_emu);
+      return;
+    }
+  }
+  store_rows<DHP>(dst, dqacc, p.scale, Dh, lane);
 }
 
 // ---- backward: dK, dV ---------------------------------------------------------------------------
@@ -881,8 +939,15 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_
     else dkdv_tile<DHP, 1, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, nfull * 64, sbase, krow, lane);
   }
   if (krow >= S) return;
-  store_rows<DHP>((bf16*)p.dk + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dkacc, p.scale, Dh, lane);
   store_rows<DHP>((bf16*)p.dv + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dvacc, 1.f, Dh, lane);
+  bf16* dst = (bf16*)p.dk + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss;
+  if constexpr (DHP == 64) {
+    if (p.rope) {
+      store_rows_rope64(dst, dkacc, p.scale, lane, p.rope, krow - p.rope_prefix, S - p.rope_prefix, p.rope_emu);
+      return;
+    }
+  }
+  store_rows<DHP>(dst, dkacc, p.scale, Dh, lane);
 }
 
 #undef MFMA
@@ -903,6 +968,7 @@ static AttnP make_p(const VitkAttn* a) {
   p.seed = a->seed; p.scale = a->scale;
   p.thr = a->drop_p > 0.f ? drop_threshold(a->drop_p) : 0;
   p.keep_scale = 1.f / (1.f - a->drop_p);
+  p.rope = a->rope; p.rope_prefix = (int)a->rope_prefix; p.rope_emu = a->rope_emulate_bf16;
   return p;
 }
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -995,6 +1061,9 @@ extern "C" int vitk_attn_bwd(const VitkAttn* a, void* stream) {
   const int64_t rows = a->B * a->H * a->S;
   const bool can = attn_mfma_ok(a, true);
   VITK_REQUIRE(a->algo != 2 || can, "attn_bwd: MFMA kernel cannot take this problem (dtype/alignment/head_dim)");
+  if (a->rope)
+    VITK_REQUIRE(can && a->algo != 1 && a->Dh == 64 && a->rope_prefix >= 0 && a->rope_prefix < a->S && ((uintptr_t)a->rope & 15) == 0,
+                 "attn_bwd: the fused inverse rotation needs the MFMA kernels, head_dim 64 and 0 <= rope_prefix < S");
   if (can && a->algo != 1) {
     const int nw = pick_nw(a->S, a->Dh, false);
     dim3 grid(head_block_grid(a->B, a->H, a->S, nw * 32));

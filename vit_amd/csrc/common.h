@@ -32,6 +32,15 @@ template <class T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
 __device__ __forceinline__ float round_bf16(float v) { return (float)((bf16)v); }
+// One output element of apply_rope (vit/rope.py:148-163), x * cos + rotate_half(x) * sin, the way eager elementwise ops
+// compute it: two rounded products and a rounded sum, never contracted into an fma, so that every kernel that rotates
+// (the stand-alone pass, the projection epilogue, the attention backward stores) produces the same bits.
+// emu: the products are rounded to bf16 before the sum (a bf16 table in the reference).
+__device__ __forceinline__ float rope_mix(float x, float c, float y, float s, int emu) {
+  float a = __fmul_rn(x, c), b = __fmul_rn(y, s);
+  if (emu) { a = round_bf16(a); b = round_bf16(b); }
+  return __fadd_rn(a, b);
+}
 // value as the dtype T would hold it
 template <class T> __device__ __forceinline__ float round_as(float v) { return to_f<T>(from_f<T>(v)); }
 

@@ -626,13 +626,8 @@ __global__ __launch_bounds__(256) void rope_rows_k(T* __restrict__ x, const floa
       const float x1 = to_f<T>(px[d + j]), x2 = to_f<T>(px[d + j + half]);
       const float s1 = ps[d + j], s2 = ps[d + j + half], c1 = pc[d + j], c2 = pc[d + j + half];
       float o1, o2;
-      if (!inverse) {
-        if (emu) { o1 = round_bf16(x1 * c1) + round_bf16(-x2 * s1); o2 = round_bf16(x2 * c2) + round_bf16(x1 * s2); }
-        else { o1 = x1 * c1 - x2 * s1; o2 = x2 * c2 + x1 * s2; }
-      } else {
-        if (emu) { o1 = round_bf16(x1 * c1) + round_bf16(x2 * s2); o2 = round_bf16(x2 * c2) + round_bf16(-x1 * s1); }
-        else { o1 = x1 * c1 + x2 * s2; o2 = x2 * c2 - x1 * s1; }
-      }
+      if (!inverse) { o1 = rope_mix(x1, c1, -x2, s1, emu); o2 = rope_mix(x2, c2, x1, s2, emu); }
+      else { o1 = rope_mix(x1, c1, x2, s2, emu); o2 = rope_mix(x2, c2, -x1, s1, emu); }
       px[d + j] = from_f<T>(o1);
       px[d + j + half] = from_f<T>(o2);
     }
@@ -673,13 +668,8 @@ __global__ __launch_bounds__(256) void rope_rows4_k(T* __restrict__ x, const flo
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const float a = x1.v[j], bb = x2.v[j];
-      if (!inverse) {
-        if (emu) { o1.v[j] = round_bf16(a * c1v[j]) + round_bf16(-bb * s1v[j]); o2.v[j] = round_bf16(bb * c2v[j]) + round_bf16(a * s2v[j]); }
-        else { o1.v[j] = a * c1v[j] - bb * s1v[j]; o2.v[j] = bb * c2v[j] + a * s2v[j]; }
-      } else {
-        if (emu) { o1.v[j] = round_bf16(a * c1v[j]) + round_bf16(bb * s2v[j]); o2.v[j] = round_bf16(bb * c2v[j]) + round_bf16(-a * s1v[j]); }
-        else { o1.v[j] = a * c1v[j] + bb * s2v[j]; o2.v[j] = bb * c2v[j] - a * s1v[j]; }
-      }
+      if (!inverse) { o1.v[j] = rope_mix(a, c1v[j], -bb, s1v[j], emu); o2.v[j] = rope_mix(bb, c2v[j], a, s2v[j], emu); }
+      else { o1.v[j] = rope_mix(a, c1v[j], bb, s2v[j], emu); o2.v[j] = rope_mix(bb, c2v[j], -a, s1v[j], emu); }
     }
     o1.store(px + d);
     o2.store(px + d + half);

@@ -587,12 +587,13 @@ static bool mfma_ok(const VitkGemm* g) {
   if (g->trans_a && !g->trans_b) return false;  // A^T x B^T-layout never occurs on the path
   const int ep = g->epilogue;
   const bool nt = !g->trans_a && !g->trans_b, nn = !g->trans_a && g->trans_b;
-  if ((ep == VITK_EPI_RESIDUAL || ep == VITK_EPI_PATCH || ep == VITK_EPI_ACT || ep == VITK_EPI_GLU) && !nt) return false;
+  if ((ep == VITK_EPI_RESIDUAL || ep == VITK_EPI_PATCH || ep == VITK_EPI_ACT || ep == VITK_EPI_GLU || ep == VITK_EPI_ROPE) && !nt) return false;
+  if (ep == VITK_EPI_ROPE && g->out_dtype != VITK_BF16) return false;
   if ((ep == VITK_EPI_DACT || ep == VITK_EPI_DGLU) && !nn) return false;
   if (ep == VITK_EPI_GLU && g->N % 64) return false;
   // the epilogue moves 4 columns per lane with vector accesses, 8 for bf16 outputs of STORE / GLU / DGLU
   if (g->N % 4 || g->ldo % 4) return false;
-  if (g->out_dtype == VITK_BF16 && (ep == VITK_EPI_STORE || ep == VITK_EPI_GLU || ep == VITK_EPI_DGLU) && (g->N % 8 || g->ldo % 8))
+  if (g->out_dtype == VITK_BF16 && (ep == VITK_EPI_STORE || ep == VITK_EPI_GLU || ep == VITK_EPI_DGLU || ep == VITK_EPI_ROPE) && (g->N % 8 || g->ldo % 8))
     return false;
   if (!aligned16(g->out) || !aligned16(g->res) || !aligned16(g->aux) || !aligned16(g->bias) || !aligned16(g->gamma) ||
       !aligned16(g->pos))
@@ -662,6 +663,7 @@ static Epi make_epi(const VitkGemm* g) {
   e.act = g->act; e.use_limit = g->use_limit; e.use_extra = g->use_extra; e.limit = g->limit; e.extra = g->extra_bias;
   e.asum = g->a_colsum; e.asum_partial = nullptr; e.m_off = 0;
   e.pos_f32 = g->pos_f32 || g->in_dtype == VITK_F32;
+  e.rope = g->rope; e.rope_width = g->rope_width; e.rope_emu = g->rope_emulate_bf16;
   return e;
 }
 
@@ -768,7 +770,7 @@ static void launch_mfma_layout(const VitkGemm* g, const Epi& e, int splits, int6
 static int64_t ragged_round_cut(const VitkGemm* g) {
   if (g->algo != 0 && g->algo != 2) return 0;
   if (g->trans_a || !use_tile256(g)) return 0;
-  if (g->epilogue != VITK_EPI_STORE && g->epilogue != VITK_EPI_RESIDUAL) return 0;
+  if (g->epilogue != VITK_EPI_STORE && g->epilogue != VITK_EPI_RESIDUAL && g->epilogue != VITK_EPI_ROPE) return 0;
   if (pick_splits(g) != 1) return 0;
   const int64_t cus = cu_count(), tm = ceil_div(g->M, BM2), tn = ceil_div(g->N, BN2);
   const int64_t tiles = tm * tn, rounds = tiles / cus, rem = tiles % cus;
@@ -818,6 +820,9 @@ static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st) {
   else if (g->epilogue == VITK_EPI_GLU) launch_mfma_one<false, false, VITK_EPI_GLU, TO>(g, e, 1, klen, nullptr, st);
   else if (g->epilogue == VITK_EPI_DACT) launch_mfma_one<false, true, VITK_EPI_DACT, TO>(g, e, 1, klen, nullptr, st);
   else if (g->epilogue == VITK_EPI_DGLU) launch_mfma_one<false, true, VITK_EPI_DGLU, TO>(g, e, 1, klen, nullptr, st);
+  else if (g->epilogue == VITK_EPI_ROPE) {
+    if constexpr (sizeof(TO) == 2) launch_mfma_one<false, false, VITK_EPI_ROPE, TO>(g, e, 1, klen, nullptr, st);
+  }
   else if (!g->trans_a && !g->trans_b) launch_mfma_layout<false, false, TO>(g, e, splits, klen, st);
   else if (!g->trans_a && g->trans_b) launch_mfma_layout<false, true, TO>(g, e, splits, klen, st);
   else launch_mfma_layout<true, true, TO>(g, e, splits, klen, st);
@@ -828,8 +833,8 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   VITK_REQUIRE(g && g->a && g->b && g->out, "gemm: null pointer");
   VITK_REQUIRE(g->M >= 0 && g->N > 0 && g->K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)g->M, (long long)g->N,
                (long long)g->K);
-  VITK_REQUIRE(g->epilogue >= 0 && g->epilogue <= 6, "gemm: unknown epilogue %d", g->epilogue);
-  const bool fusedact = g->epilogue >= VITK_EPI_ACT;
+  VITK_REQUIRE(g->epilogue >= 0 && g->epilogue <= 7, "gemm: unknown epilogue %d", g->epilogue);
+  const bool fusedact = g->epilogue >= VITK_EPI_ACT && g->epilogue <= VITK_EPI_DGLU;
   VITK_REQUIRE(g->in_dtype == VITK_F32 || g->in_dtype == VITK_BF16, "gemm: bad in_dtype %d", g->in_dtype);
   VITK_REQUIRE(g->out_dtype == VITK_F32 || g->out_dtype == VITK_BF16, "gemm: bad out_dtype %d", g->out_dtype);
   VITK_REQUIRE(!(g->in_dtype == VITK_F32 && g->out_dtype == VITK_BF16), "gemm: fp32 operands with bf16 output unsupported");
@@ -843,6 +848,12 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   if (g->epilogue == VITK_EPI_PATCH)
     VITK_REQUIRE(g->tokens > 0 && g->M % g->tokens == 0 && g->seq >= g->prefix + g->tokens,
                  "gemm: PATCH epilogue needs tokens | M and seq >= prefix + tokens");
+  if (g->epilogue == VITK_EPI_ROPE)
+    VITK_REQUIRE(g->rope && g->rope_width > 0 && g->rope_width % 64 == 0 && g->N % 64 == 0 && g->seq > 0 && g->prefix >= 0 &&
+                     g->prefix < g->seq && g->in_dtype == VITK_BF16 && g->out_dtype == VITK_BF16 && !g->trans_a && !g->trans_b &&
+                     ((uintptr_t)g->rope & 15) == 0,
+                 "gemm: ROPE epilogue needs a table, bf16 operands and output, row-major A and nn.Linear-layout B, sections "
+                 "of whole 64-column heads and 0 <= prefix < seq");
   if (g->pos_f32) VITK_REQUIRE(g->epilogue == VITK_EPI_PATCH && g->out_dtype == VITK_F32, "gemm: pos_f32 needs the PATCH epilogue and a float32 output");
   if (g->a_colsum) VITK_REQUIRE(g->trans_a && g->epilogue == VITK_EPI_STORE, "gemm: a_colsum needs trans_a = 1 and the STORE epilogue");
   if (g->M == 0) return 0;
@@ -851,6 +862,7 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
   const bool can = mfma_ok(g);
   VITK_REQUIRE(g->algo < 2 || can, "gemm: MFMA kernel cannot take this problem (dtype/alignment/layout)");
   VITK_REQUIRE(!fusedact || (can && g->algo != 1), "gemm: fused activation epilogues exist in the MFMA kernel only");
+  VITK_REQUIRE(g->epilogue != VITK_EPI_ROPE || (can && g->algo != 1), "gemm: the ROPE epilogue exists in the MFMA kernel only");
   if (can && g->algo != 1) {
     if (g->out_dtype == VITK_F32) launch_mfma<float>(g, e, st);
     else launch_mfma<bf16>(g, e, st);

@@ -21,6 +21,9 @@ struct Epi {
   float* asum_partial;   // split-K: per-split partial sums [splits][M]
   int64_t m_off;         // row of the whole problem that this launch's row 0 is (dropout stream index)
   int pos_f32;           // PATCH: the position table holds fp32 values and is added without rounding (output fp32)
+  const float* rope;     // ROPE: [2, seq - prefix, 64] sin then cos
+  int64_t rope_width;    // ROPE: columns per section (q | k | v); sections 0 and 1 are rotated, heads of 64 columns
+  int rope_emu;          // ROPE: round each product to bf16 before the sum (a bf16 table in the reference)
 };
 
 // sum of a fragment's 8 bf16 values added to s (4 x v_dot2c_f32_bf16 against ones)
@@ -55,6 +58,7 @@ __device__ __forceinline__ void asum_store(const Epi& e, const float (&rs)[NI], 
 
 
 constexpr int EPI_ACT = VITK_EPI_ACT, EPI_GLU = VITK_EPI_GLU, EPI_DACT = VITK_EPI_DACT, EPI_DGLU = VITK_EPI_DGLU;
+constexpr int EPI_ROPE = VITK_EPI_ROPE;
 
 // Vector form used by the MFMA kernel: 4 consecutive columns n..n+3 of row m (n % 4 == 0).
 //   STORE / RESIDUAL / PATCH as EpiOp above;
@@ -303,7 +307,7 @@ __device__ __forceinline__ uint32_t clip32(int64_t v) { return v > 0xfffffff0ll 
 // slab (the epilogues are paced by the issue of their stores).  Used by STORE with bf16 output, GLU and DGLU; their
 // arithmetic (and rounding points) is that of the 4-column forms above.
 template <int MODE, class TO>
-constexpr bool epi_wide() { return MODE == EPI_GLU || MODE == EPI_DGLU || (MODE == VITK_EPI_STORE && sizeof(TO) == 2); }
+constexpr bool epi_wide() { return MODE == EPI_GLU || MODE == EPI_DGLU || MODE == EPI_ROPE || (MODE == VITK_EPI_STORE && sizeof(TO) == 2); }
 
 struct Raw8 {   // 8 bf16 as loaded
   uint4 q;
@@ -429,6 +433,11 @@ struct EpiCols {  // per-lane column constants, loaded once per tile
           b.load((const bf16*)e.bias + ncol);
 #pragma unroll
           for (int j = 0; j < 8; j++) wb0[j] = b.get(j);
+          if (MODE == EPI_ROPE) {   // the rotation partner's columns: the other half of the same 64-column head
+            b.load((const bf16*)e.bias + (ncol ^ 32));
+#pragma unroll
+            for (int j = 0; j < 8; j++) wb1[j] = b.get(j);
+          }
         }
       }
     } else if (MODE == EPI_GLU) {
@@ -529,6 +538,7 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
     }
   } else if (epi_wide<MODE, TO>()) {
     const int cv = lane & 7, rr = lane >> 3;
+    const int rope_t0 = MODE == EPI_ROPE ? (int)((mbase + e.m_off) % e.seq) : 0;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
       const int row = it * 8 + rr;
@@ -541,6 +551,31 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
         else {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
+          if (MODE == EPI_ROPE) {
+            // rotate_half on the q and k sections of the rows behind the prefix (vit/rope.py:148-163): the linear's output
+            // as bf16 holds it, then  o[d] = x[d] cos[d] - x[d + 32] sin[d]  (d < 32),  o[d] = x[d] cos[d] + x[d - 32] sin[d]
+            int tok = rope_t0 + row;              // index of the row inside its sample: one division per slab
+            while (tok >= (int)e.seq) tok -= (int)e.seq;
+            tok -= (int)e.prefix;
+            if (tok >= 0 && ncol < 2 * e.rope_width) {
+              float u[8];
+              *(float4*)u = *(const float4*)(stg + row * STG_LD + 8 * (cv ^ 4));
+              *(float4*)(u + 4) = *(const float4*)(stg + row * STG_LD + 8 * (cv ^ 4) + 4);
+              const float* sn = e.rope + tok * 64 + 8 * cv;
+              const float* cs = sn + (e.seq - e.prefix) * 64;
+              float sv[8], cw[8];
+              *(float4*)sv = *(const float4*)sn;
+              *(float4*)(sv + 4) = *(const float4*)(sn + 4);
+              *(float4*)cw = *(const float4*)cs;
+              *(float4*)(cw + 4) = *(const float4*)(cs + 4);
+              const float sign = (cv & 4) ? 1.f : -1.f;
+#pragma unroll
+              for (int j = 0; j < 8; j++) {
+                const float x = round_as<bf16>(v[j]), y = sign * round_as<bf16>(u[j] + cols.wb1[j]);
+                v[j] = rope_mix(x, cw[j], y, sv[j], e.rope_emu);
+              }
+            }
+          }
           store8((bf16*)e.out + m * e.ldo + ncol, v);
         }
       }

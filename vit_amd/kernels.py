@@ -6,6 +6,7 @@ memory), and pass raw pointers + sizes + the current HIP stream.  No arithmetic 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -110,8 +111,10 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
          pos: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
          tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None,
          tag: str = "", act: int = 0, limit: Optional[float] = None, extra: Optional[float] = None,
-         a_colsum: Optional[Tensor] = None) -> Tensor:
-    """``a_colsum`` ([M], dtype of out; trans_a products only) receives sum_k A[k, m] from the same pass."""
+         a_colsum: Optional[Tensor] = None, rope: Optional[Tensor] = None, rope_width: int = 0,
+         rope_emulate_bf16: bool = False) -> Tensor:
+    """``a_colsum`` ([M], dtype of out; trans_a products only) receives sum_k A[k, m] from the same pass.
+    ``rope`` (EPI_ROPE): fp32 table [2, seq - prefix, 64]; sections of ``rope_width`` columns, the first two rotated."""
     lib = L.load()
     L.require_gpu(a, b, out, bias, res, gamma, aux, pos, a_colsum)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1, "gemm operands must be row-major 2-D"
@@ -143,6 +146,10 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     g.algo = _ALGO if algo is None else algo
     g.dynamic_tiles = int(_DYNAMIC_TILES)
     g.pos_f32 = int(pos_f32)
+    if rope is not None:
+        L.require_gpu(rope)
+        assert rope.dtype == torch.float32 and rope.is_contiguous() and tuple(rope.shape) == (2, seq - prefix, 64)
+    g.rope, g.rope_width, g.rope_emulate_bf16 = L.ptr(rope), rope_width, int(rope_emulate_bf16)
     g.workspace, g.workspace_bytes = None, 0
     need = lib.vitk_gemm_workspace_bytes(C.byref(g))
     if need:
@@ -157,6 +164,14 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
         return out
     L.check(lib.vitk_gemm(C.byref(g), L.stream()))
     return out
+
+
+def can_fuse_rope(dtype: torch.dtype, Dh: int, table: Optional[Tensor]) -> bool:
+    """The QKV GEMM can rotate q and k in its epilogue, and the attention backward un-rotate dq and dk in its stores, for
+    bf16 operands, head_dim 64 and one table shared by all samples."""
+    if os.environ.get("VITK_NO_ROPE_FUSE"):   # measurements: the rotation as a pass of its own
+        return False
+    return table is not None and table.dim() == 3 and dtype == torch.bfloat16 and _ALGO != 1 and Dh == 64
 
 
 def can_fuse_activation(dtype: torch.dtype, D: int, F: int) -> bool:
@@ -195,8 +210,10 @@ def attn_fwd(qkv: Tensor, B: int, S: int, H: int, Dh: int, scale: float, drop_p:
 
 
 def attn_bwd(qkv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, S: int, H: int, Dh: int, scale: float,
-             drop_p: float = 0.0, seed: int = 0, algo: Optional[int] = None) -> Tensor:
-    """Returns dqkv in the packed layout of qkv."""
+             drop_p: float = 0.0, seed: int = 0, algo: Optional[int] = None, rope: Optional[Tensor] = None,
+             rope_emulate_bf16: bool = False) -> Tensor:
+    """Returns dqkv in the packed layout of qkv.  ``rope`` (fp32 [2, S - prefix, 64]): q and k were rotated with this
+    table before the attention; dq and dk come back through the transposed rotation."""
     lib = L.load()
     L.require_gpu(qkv, o, lse, dout)
     dout = _c(dout)
@@ -209,6 +226,10 @@ def attn_bwd(qkv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, S: int, 
     base = dqkv.data_ptr()
     a.dq, a.dk, a.dv = base, base + D * es, base + 2 * D * es
     a.dq_sb, a.dq_sh, a.dq_ss = S * 3 * D, Dh, 3 * D
+    if rope is not None:
+        L.require_gpu(rope)
+        assert rope.dtype == torch.float32 and rope.is_contiguous() and rope.dim() == 3 and rope.shape[2] == Dh == 64
+        a.rope, a.rope_prefix, a.rope_emulate_bf16 = L.ptr(rope), S - rope.shape[1], int(rope_emulate_bf16)
     L.check(lib.vitk_attn_bwd(C.byref(a), L.stream()))
     return dqkv
 

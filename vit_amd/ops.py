@@ -335,7 +335,15 @@ class AttentionSublayerFn(torch.autograd.Function):
                                     opt["layernorm"], tc, rows)
         wq, bq, wo, bo = _cast_param(w_qkv, tc), _cast_param(b_qkv, tc), _cast_param(w_out, tc), _cast_param(b_out, tc)
         qkv = torch.empty((M, 3 * D), dtype=tc, device=x.device)
-        K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv")
+        table, emu = _rope_table(rope, keep_idx, B, Bk, tc)
+        # head_dim 64, one table for all samples: q and k are rotated in the projection's epilogue and their gradients
+        # un-rotated in the attention backward's stores; otherwise the rotation is a pass of its own over q and k
+        fuse_rope = qn_w is None and K.can_fuse_rope(tc, Dh, table)
+        if fuse_rope:
+            K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv", epilogue=L.EPI_ROPE,
+                   rope=table, rope_width=D, rope_emulate_bf16=emu, seq=S, prefix=S - table.shape[-2])
+        else:
+            K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv")
         # per-head q/k normalisation over Dh, before RoPE (vit/attention.py:25-41, :95-105).  The heads of q (and of k)
         # are copied out as a contiguous [M*H, Dh] matrix, which is what the row-norm kernels take and what their
         # backward needs; the normalised rows go back into the packed buffer.
@@ -348,8 +356,7 @@ class AttentionSublayerFn(torch.autograd.Function):
                                          opt["qk_layernorm"], tc)
                 qkv[:, which * D:(which + 1) * D].copy_(nrm.view(M, D))
                 qk_saved += [pre, r_, m_]
-        table, emu = _rope_table(rope, keep_idx, B, Bk, tc)
-        if table is not None:
+        if table is not None and not fuse_rope:
             K.rope_qk_(qkv, table, Bk, S, H, Dh, S - table.shape[-2], False, emu)
         seed_a = next_seed(x.device) if p_attn > 0 else 0
         o, lse = K.attn_fwd(qkv, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
@@ -364,7 +371,7 @@ class AttentionSublayerFn(torch.autograd.Function):
             y = out.view(Bk, S, D)
         ctx.save_for_backward(x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows, qn_w, kn_w, *qk_saved)
         ctx.meta = (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, x.dtype, w_qkv.dtype,
-                    norm_b is not None, b_qkv is not None, b_out is not None, qn_b is not None, kn_b is not None)
+                    norm_b is not None, b_qkv is not None, b_out is not None, qn_b is not None, kn_b is not None, fuse_rope)
         ctx.ptrs = _ptrs(w_qkv, b_qkv, w_out, b_out)
         return y
 
@@ -373,7 +380,7 @@ class AttentionSublayerFn(torch.autograd.Function):
         (x2, norm_w, rstd, mean, xn, qkv, o, lse, wq, wo, g, aux, table, rows, qn_w, kn_w, pre_q, rstd_q, mean_q, pre_k,
          rstd_k, mean_k) = ctx.saved_tensors
         (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, xdtype, wdtype, has_nb, has_bq,
-         has_bo, has_qnb, has_knb) = ctx.meta
+         has_bo, has_qnb, has_knb, fuse_rope) = ctx.meta
         need = ctx.needs_input_grad
         ptrs = ctx.ptrs
         M = Bk * S
@@ -382,8 +389,9 @@ class AttentionSublayerFn(torch.autograd.Function):
         dy, dgamma = _residual_grad(dnew2, tc, g if residual else None, rows if residual else None, M,
                                     opt["alpha"] if residual else 1.0, p_hid, seed_h, aux, need[7], _carried_bf16(dnew, D))
         do, dwo, dbo = _linear_bwd(dy, o, wo, True, need[5], has_bo and need[6], wdtype, tag="out", w_ptr=ptrs[2], b_ptr=ptrs[3])
-        dqkv = K.attn_bwd(qkv, o, lse, do, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a)
-        if table is not None:
+        dqkv = K.attn_bwd(qkv, o, lse, do, Bk, S, H, Dh, Dh ** -0.5, p_attn, seed_a, rope=table if fuse_rope else None,
+                          rope_emulate_bf16=emu)
+        if table is not None and not fuse_rope:
             K.rope_qk_(dqkv, table, Bk, S, H, Dh, S - table.shape[-2], True, emu)
         dqn = [None, None, None, None]   # d q_norm.weight, d q_norm.bias, d k_norm.weight, d k_norm.bias
         if qn_w is not None:

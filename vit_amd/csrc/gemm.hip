@@ -12,6 +12,7 @@
 #include "common.h"
 #include <string.h>
 
+#include <type_traits>
 #include "gemm_epi.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -371,13 +372,17 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
   if (TA && asum_on) asum_store<4, MODE, TO>(e, rs, m0 + wm * 128, M, split, lane);
   float* stg = (float*)smem + wid * (32 * STG_LD);
   SlabPre<MODE, TO> pre;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
+  auto one_slab = [&](auto ic) {   // a compile-time slab index: see gemm_mfma256d_k
+    constexpr int i = decltype(ic)::value;
     const int64_t mbase = m0 + wm * 128 + i * 32;
     slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
     slab_stage(stg, acc[i][0], acc[i][1], lane);
     slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
-  }
+  };
+  one_slab(std::integral_constant<int, 0>{});
+  one_slab(std::integral_constant<int, 1>{});
+  one_slab(std::integral_constant<int, 2>{});
+  one_slab(std::integral_constant<int, 3>{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -528,13 +533,19 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   }
   float* stg = (float*)smem + wid * (32 * STG_LD);
   SlabPre<MODE, TO> pre;
-#pragma unroll
-  for (int sl = 0; sl < 4; sl++) {
+  // the four slabs, spelled out: a slab index that is not a compile-time constant would index the accumulator array
+  // dynamically and send all of it to scratch memory (the unroll pragma alone is not honoured for the largest epilogues)
+  auto one_slab = [&](auto slc) {
+    constexpr int sl = decltype(slc)::value;
     const int64_t mbase = m0 + wm * 128 + sl * 32;
     slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
     slab_stage16(stg, acc, sl, lane);
     slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
-  }
+  };
+  one_slab(std::integral_constant<int, 0>{});
+  one_slab(std::integral_constant<int, 1>{});
+  one_slab(std::integral_constant<int, 2>{});
+  one_slab(std::integral_constant<int, 3>{});
   STAMP(4)
   if (dynamic && tid == 0) s_next = drawn;
   __syncthreads();   // the staging slabs overlay the ring: done before the next tile's first requests
@@ -686,7 +697,6 @@ static void launch_simple(const VitkGemm* g, const Epi& e, hipStream_t st) {
 static bool use_tile256(const VitkGemm* g) {
   if (g->algo == 3 || g->algo == 5) return true;
   if (g->algo == 4) return false;
-  if (g->epilogue == VITK_EPI_DGLU) return false;   // its epilogue does not fit the register budget beside 128 accumulators
   // measured on MI355X (ViT-B shapes): the 256^2 tile wins once the output is wide or the contraction long;
   // narrow, short problems (N = K = 768) keep more CUs busy with 128^2 tiles
   return g->M >= 512 && g->N >= 512 && (g->N >= 1024 || g->K >= 2048);

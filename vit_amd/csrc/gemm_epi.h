@@ -477,7 +477,7 @@ struct EpiCols {  // per-lane column constants, loaded once per tile
 template <int MODE, class TO>
 struct SlabPre {
   EpiPre<(MODE < 0 ? 0 : MODE), TO> r[8];
-  Raw8 wa[4], wb[4];   // 8-column DGLU: 4 rows per lane, linear and gate pre-activations
+  Raw8 wa[2], wb[2];   // 8-column DGLU: linear and gate pre-activations of the row being finished and of the next one
 };
 
 template <int MODE>
@@ -488,15 +488,11 @@ __device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, 
                                               int64_t mbase, int64_t M, int64_t N, int lane) {
   if (!epi_reads_memory<MODE>()) return;
   constexpr int EMODE = MODE < 0 ? 0 : MODE;
-  if (epi_wide<MODE, TO>()) {   // DGLU
-    const int rr = lane >> 3;
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int64_t m = mbase + it * 8 + rr;
-      if (m < M && cols.ncol < N) {
-        pre.wa[it].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol);
-        pre.wb[it].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol);
-      }
+  if (epi_wide<MODE, TO>()) {   // DGLU: the slab's first row per lane; slab_finish requests the others one ahead of their use
+    const int64_t m = mbase + (lane >> 3);
+    if (m < M && cols.ncol < N) {
+      pre.wa[0].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol);
+      pre.wb[0].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol);
     }
     return;
   }
@@ -518,7 +514,7 @@ __device__ __forceinline__ void slab_stage(float* stg, const f32x16& a0, const f
 }
 
 template <int MODE, class TO>
-__device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO>& cols, const SlabPre<MODE, TO>& pre,
+__device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO>& cols, SlabPre<MODE, TO>& pre,
                                             const float* stg, int64_t mbase, int64_t nwave, int64_t M, int64_t N,
                                             int64_t split, float* __restrict__ partial, int lane) {
   constexpr int EMODE = MODE < 0 ? 0 : MODE;
@@ -546,8 +542,12 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
       float v[8];
       *(float4*)v = *(const float4*)(stg + row * STG_LD + 8 * cv);
       *(float4*)(v + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
+      if (MODE == EPI_DGLU && it < 3 && m + 8 < M && ncol < N) {   // the next row's pre-activations, one step ahead
+        pre.wa[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * 2 * e.N + ncol);
+        pre.wb[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * 2 * e.N + e.N + ncol);
+      }
       if (m < M && ncol < N) {
-        if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, v, pre.wa[it], pre.wb[it]);
+        if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, v, pre.wa[it & 1], pre.wb[it & 1]);
         else {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];

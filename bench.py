@@ -36,6 +36,12 @@ WORKLOADS = {
                  num_attention_heads=12, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="fourier",
                  num_register_tokens=16, dtype="float32"),
         autocast=True, batch=256),
+    # BASELINE config 1: the reference's own CPU-runnable case, forward only (plumbing; fp32 takes the portable kernels)
+    "vit_s16_224_fp32_fwd": dict(
+        cfg=dict(in_channels=3, patch_size=(16, 16), img_size=(224, 224), depth=12, hidden_size=384, ffn_hidden_size=1536,
+                 num_attention_heads=6, hidden_dropout=0.0, attention_dropout=0.0, activation="gelu", pos_enc="fourier",
+                 dtype="float32"),
+        autocast=False, batch=8, forward_only=True),
     # BASELINE config 3 / 4 / 5 shapes (secondary; pure bf16 parameters)
     "vit_l16_384_srelu_rope": dict(
         cfg=dict(in_channels=3, patch_size=(16, 16), img_size=(384, 384), depth=24, hidden_size=1024, ffn_hidden_size=4096,
@@ -80,20 +86,37 @@ def make_model(w: dict, device):
     return cfg, model.train()
 
 
-def fc1_kernel_name(c: dict) -> str:
-    """The kernel behind the "fc1" tag: the 256x256-tile LDS-DMA GEMM with the activation fused in its epilogue."""
+def fc1_kernel_name(c: dict, autocast: bool) -> str:
+    """The kernel behind the "fc1" tag: the 256x256-tile LDS-DMA GEMM with the activation fused in its epilogue; fp32
+    parameters without autocast run the portable fp32 kernel."""
+    if c["dtype"] == "float32" and not autocast:
+        return "gemm_simple_k<float> (fc1 forward, portable fp32 kernel)"
     epi = "GLU" if c["activation"].endswith("glu") else "ACT"
     return f"gemm_mfma256d_k<NT,{epi},bf16> (fc1 forward)"
 
 
-def measured_traffic(workload: str, batch: int):
-    """HBM-side bytes per fc1 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate
-    runs, gfx950 correction applied); None for a workload / batch the passes were not taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_fc1_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+FC1_KERNEL_ROW = "gemm_mfma256d_k<false, false, 4, bf16>"   # its name in tools/pmc_summary.py's table
+
+
+def counter_summary(workload: str, batch: int):
+    """Figures that only hardware counters give, from the committed summary of separate rocprofv3 --pmc passes over
+    this same command (tools/pmc_collect.sh, tools/pmc_summary.py): memory-side bytes per fc1 launch (FETCH_SIZE with
+    the gfx950 correction + WRITE_SIZE) and the matrix-unit busy fractions.  They are not measured by this run -- a
+    process cannot read the counters of its own kernels -- so the build they were taken on is reported beside them.
+    (None, None) for a workload / batch the passes were not taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)
     if workload != "vit_b14_224_swiglu_reg16_fourier" or batch != 256 or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
-        return json.load(f).get("traffic_bytes_per_launch")
+        summ = json.load(f)
+    row = next((k for k in summ["kernels"] if k["kernel"] == FC1_KERNEL_ROW), None)
+    traffic = None if row is None else row["read_bytes_per_call"] + row["write_bytes_per_call"]
+    util = {"whole_step_mfma_busy_frac": summ["whole_run"]["mfma_busy_frac"],
+            "fc1_mfma_busy_frac": None if row is None else row["mfma_busy_frac"],
+            "definition": summ["formulas"]["mfma_busy_frac"], "source": PMC_SUMMARY,
+            "taken_on_build": summ["build"]}
+    return traffic, util
 
 
 def cpu_baseline(w: dict, seconds: float = 20.0) -> dict:
@@ -108,16 +131,22 @@ def cpu_baseline(w: dict, seconds: float = 20.0) -> dict:
     B = 8
     x = torch.randn(B, cfg.in_channels, *cfg.img_size).to(cfg.dtype)
     ac = torch.bfloat16 if w["autocast"] else None
-    O.run_fwd_bwd(cfg, sd, x, training=True, autocast=ac, loss="mean")  # warm-up
+    if w.get("forward_only"):
+        def run():
+            with torch.no_grad():
+                O.vit_forward(cfg, sd, x, training=False)
+    else:
+        run = lambda: O.run_fwd_bwd(cfg, sd, x, training=True, autocast=ac, loss="mean")  # noqa: E731
+    run()  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        O.run_fwd_bwd(cfg, sd, x, training=True, autocast=ac, loss="mean")
+        run()
         n += 1
         el = time.perf_counter() - t0
         if el > seconds or n >= 16:
             break
     return {"value": round(n * B / el, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} fwd+bwd steps of batch {B}, same model/mode, torch {torch.__version__} eager CPU ops "
+            "sample": f"{n} {'forward' if w.get('forward_only') else 'fwd+bwd'} steps of batch {B}, same model/mode, torch {torch.__version__} eager CPU ops "
                       f"({os.cpu_count()} logical CPUs visible)"}
 
 
@@ -167,7 +196,15 @@ def main() -> None:
     in_dtype = torch.float32 if w["autocast"] else cfg.dtype
     x = torch.randn(B, cfg.in_channels, *cfg.img_size, device=device, dtype=in_dtype)
 
+    fwd_only = bool(w.get("forward_only"))
+    if fwd_only:
+        model.eval()
+
     def step():
+        if fwd_only:
+            with torch.no_grad():
+                model(x)
+            return
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=w["autocast"]):
             out = model(x)
             loss = out.dense_features.mean()
@@ -213,20 +250,24 @@ def main() -> None:
     if rank == 0:
         imgs = B * world * args.steps / elapsed
         fpi = flops_per_image(c)
+        traffic, mfma_util = counter_summary(args.workload, B)
         rec = {
-            "metric": "train images/sec ViT-B/14 224px bf16" if args.workload.startswith("vit_b14") else f"train images/sec {args.workload}",
+            "metric": "train images/sec ViT-B/14 224px bf16" if args.workload.startswith("vit_b14") else
+                      f"{'forward' if fwd_only else 'train'} images/sec {args.workload}",
             "value": round(imgs, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if (w["autocast"] or c["dtype"] == "bfloat16") else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "seq_len": S,
-                       "mode": "fp32 master params + torch.autocast(bf16)" if w["autocast"] else "pure bf16 params",
-                       "parallelism": f"dp{world}", "step": "fwd + mean loss + bwd + bucketed grad all-reduce + zero_grad",
-                       "fwd_bwd_gflop_per_image": round(3 * fpi / 1e9, 1)},
-            "step_mfma_frac": round(imgs / world * 3 * fpi / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": fc1_kernel_name(c), "achieved": round(achieved, 1),
+                       "mode": "fp32 master params + torch.autocast(bf16)" if w["autocast"] else f"pure {c['dtype']} params",
+                       "parallelism": f"dp{world}",
+                       "step": "forward (eval, no_grad)" if fwd_only else "fwd + mean loss + bwd + bucketed grad all-reduce + zero_grad",
+                       "fwd_bwd_gflop_per_image": round((1 if fwd_only else 3) * fpi / 1e9, 1)},
+            "step_mfma_frac": round(imgs / world * (1 if fwd_only else 3) * fpi / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": {"bound": "mfma", "kernel": fc1_kernel_name(c, w["autocast"]), "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": measured_traffic(args.workload, B), "launch_ms": round(k_ms, 4),
-                         "launches_timed": len(pairs), "flop_per_launch": k_flop},
+                         "traffic": traffic, "traffic_source": PMC_SUMMARY if traffic is not None else None,
+                         "launch_ms": round(k_ms, 4), "launches_timed": len(pairs), "flop_per_launch": k_flop},
+            "mfma_util": mfma_util,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w)

@@ -19,10 +19,19 @@ from .initialization import INIT_STD, init_linear, trunc_normal_
 PositionEncoder = str  # "fourier" | "learnable" | "none" | "rope"
 
 
+_GRIDS: dict = {}   # (dims, dtype, device, normalize) -> coordinate grid: constants, built once per process
+
+
 def create_grid(dims: Sequence[int], dtype=torch.float32, device="cpu", normalize: bool = True) -> Tensor:
-    axes = [torch.linspace(-1, 1, d, device=device, dtype=dtype) if normalize else torch.arange(d, device=device, dtype=dtype)
-            for d in dims]
-    return torch.stack(torch.meshgrid(axes, indexing="ij"), dim=-1).view(1, -1, len(dims))
+    key = (tuple(dims), dtype, str(device), normalize)
+    grid = _GRIDS.get(key)
+    if grid is None:
+        axes = [torch.linspace(-1, 1, d, device=device, dtype=dtype) if normalize else torch.arange(d, device=device, dtype=dtype)
+                for d in dims]
+        grid = torch.stack(torch.meshgrid(axes, indexing="ij"), dim=-1).view(1, -1, len(dims))
+        if len(_GRIDS) < 64:
+            _GRIDS[key] = grid
+    return grid
 
 
 def fourier_position(dims: Sequence[int], w_fourier: Tensor, w_fc1: Tensor, b_fc1: Optional[Tensor]) -> Tensor:
@@ -54,7 +63,7 @@ def fourier_features_(param: Tensor, std: float = 1.0) -> None:
     if hidden % 2:
         raise ValueError(f"Hidden size must be even, got {hidden}")
     w = param.new_empty(len(dims), hidden // 2).normal_(std=std)
-    f = create_grid(dims, dtype=param.dtype, device=param.device).squeeze_(0) @ w
+    f = create_grid(dims, dtype=param.dtype, device=param.device).squeeze(0) @ w
     param.data.copy_((torch.cat([f.sin(), f.cos()], dim=-1) / math.sqrt(hidden)).view_as(param))
 
 

@@ -72,6 +72,14 @@ def _cast(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
 _PARAM_COPIES: dict = {}
 
 
+_PARAM_CACHE_ON = os.environ.get("VITK_NO_PARAM_CACHE", "") == ""
+
+
+def clear_param_copies() -> None:
+    """Forget the kept compute-dtype copies: for code that rewrites parameters through ``.data`` (no version bump)."""
+    _PARAM_COPIES.clear()
+
+
 def _cast_param(t: Optional[Tensor], dtype: torch.dtype, make=None) -> Optional[Tensor]:
     """``_cast`` for parameters, cached per parameter.  ``make(t)`` builds the copy when it is not a plain cast (the
     zero-padded patch-embedding weight)."""
@@ -84,6 +92,8 @@ def _cast_param(t: Optional[Tensor], dtype: torch.dtype, make=None) -> Optional[
     if ent is not None and ent[0]() is t and ent[1] == key:
         return ent[2]
     c = make(t.detach()) if make is not None else t.detach().to(dtype).contiguous()
+    if not _PARAM_CACHE_ON:
+        return c
     ident = id(t)
     _PARAM_COPIES[ident] = (weakref.ref(t, lambda _r, ident=ident: _PARAM_COPIES.pop(ident, None)), key, c)
     return c

@@ -534,3 +534,17 @@ def test_gemm_dynamic_tile_shares_match_fixed_ones():
         torch.cuda.synchronize()
     finally:
         K.set_dynamic_tiles(old)
+
+
+def test_tensor_on_another_device_than_the_current_one_is_refused():
+    """Launches use the current device's stream: a tensor that lives elsewhere must be refused, not launched on."""
+    if torch.cuda.device_count() < 2:
+        # one visible GPU: the same rule is exercised through a CPU tensor, which takes the same check
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            L.require_gpu(torch.zeros(4))
+        return
+    x = torch.zeros(8, 64, device="cuda:1")
+    with pytest.raises(RuntimeError, match="current device"):
+        L.require_gpu(x)
+    with torch.cuda.device(1):
+        L.require_gpu(x)

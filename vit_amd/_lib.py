@@ -131,9 +131,21 @@ def stream() -> int:
 
 
 def require_gpu(*tensors: Optional[Tensor]) -> None:
+    """Every tensor on the GPU, and on the CURRENT one: launches go to the current device's stream and its workspace, so
+    a model on another device has to run under ``torch.cuda.device(...)`` (one process per GPU does this once)."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "vit_amd: the encoder kernels run on an MI355X (ROCm) device only; got a tensor on "
                 f"'{t.device}'. There is no CPU fallback."
+            )
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(
+                f"vit_amd: tensor on '{t.device}' but the current device is cuda:{cur}; kernels are launched on the "
+                "current device's stream. Call torch.cuda.set_device(...) (or run under torch.cuda.device(...)) first."
             )

@@ -2,8 +2,9 @@
 
 ``SelfAttention`` holds the same parameters under the same names as the reference; its forward unpacks them
 into ``attention_qkv_packed``, which runs norm -> QKV GEMM -> RoPE -> flash attention -> out_proj GEMM as one
-autograd function over libvitk kernels.  Cross-attention / attention-weight visualisation are not part of the
-encoder path and are not provided."""
+autograd function over libvitk kernels.  ``CrossAttention`` / ``AttentivePool`` (vit/attention.py:451-667) and the
+``forward_weights`` diagnostics (vit/attention.py:281-373) run through ``ops.CrossAttentionFn`` and
+``vitk_attn_weights``."""
 from __future__ import annotations
 
 from typing import Any, Optional

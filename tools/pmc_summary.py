@@ -37,9 +37,14 @@ ROLES = {   # what the instances do in the encoder step (template arguments: tra
     "gemm_mfma256d_k<false, true, 0, bf16>": "input gradients (NN)",
     "gemm_mfma256d_k<false, false, 0, bf16>": "qkv forward",
     "gemm_mfma256d_k<false, false, 1, float>": "fc2 forward + residual (fp32 stream)",
+    "gemm_mfma256d_k<false, true, 6, bf16>": "fc2 input gradient + SwiGLU backward",
+    "gemm_mfma256d_k<false, true, 5, bf16>": "fc2 input gradient + activation backward",
+    "gemm_mfma256d_k<false, false, 7, bf16>": "qkv forward + RoPE on q and k",
+    "gemm_mfma_k<false, true, -1, bf16>": "rows cut off a ragged round (NN, split-K partials)",
+    "gemm_mfma_k<false, false, 0, bf16>": "rows cut off a ragged round (qkv forward)",
     "gemm_mfma_k<false, true, 6, bf16>": "fc2 input gradient + SwiGLU backward",
     "gemm_mfma_k<false, true, 5, bf16>": "fc2 input gradient + activation backward",
-    "gemm_mfma_k<false, false, 1, float>": "out_proj forward + residual (fp32 stream)",
+    "gemm_mfma_k<false, false, 1, float>": "out_proj forward + residual (fp32 stream); rows cut off fc2's ragged round",
     "gemm_mfma_k<false, true, 0, bf16>": "small input gradients (NN, 128x128 tiles)",
 }
 

@@ -76,8 +76,9 @@ enum {
    *   DGLU (fc2 dgrad)     N = F, aux = pre-activations [M,2F]: out[m,f] = d lin, out[m,F+f] = d gate, out is [M,2F]
    * dropout index = m*F + f as in vitk_act_fwd/bwd, so fused and unfused paths draw the same mask. */
   VITK_EPI_ACT = 3, VITK_EPI_GLU = 4, VITK_EPI_DACT = 5, VITK_EPI_DGLU = 6,
-  /* ROPE (the fused QKV projection of vit/attention.py:93 followed by apply_rope on q and k, vit/rope.py:148-163, for
-   * head_dim 64; MFMA kernel only, bf16 operands and output, trans_a = trans_b = 0):
+  /* ROPE (the fused QKV projection of vit/attention.py:93 followed by the optional per-head normalisation and by
+   * apply_rope on q and k, vit/rope.py:148-163, for head_dim 64; MFMA kernel only, bf16 operands and output,
+   * trans_a = trans_b = 0):
    *   x = round(acc + bias);  rows whose index inside their sample (m % seq) is below `prefix`, and columns from
    *   2 * rope_width on (the v section), are stored as they are; elsewhere, with t = m % seq - prefix and d = n % 64,
    *   out[m,n] = x[m,n] cos[t,d] - x[m,n+32] sin[t,d]  (d < 32),   x[m,n] cos[t,d] + x[m,n-32] sin[t,d]  (d >= 32)
@@ -126,6 +127,18 @@ typedef struct VitkGemm {
   const float* rope;     /* ROPE: [2, seq - prefix, 64] float32, sin then cos (one table for all samples) */
   int64_t rope_width;    /* ROPE: columns per section, a multiple of 64 (N = 3 * rope_width for the packed q | k | v) */
   int32_t rope_emulate_bf16; /* ROPE: as in vitk_rope_qk */
+  /* ROPE epilogue, optional per-head normalisation of q and k BEFORE the rotation (_apply_qk_norm, vit/attention.py:25-41,
+   * :95-105; head_dim 64): y = (x - mean) * rstd * w (+ b) over the 64 columns of a head, x = round(acc + bias), the result
+   * rounded to bf16 -- bit-identical to vitk_norm_fwd on the heads copied out as [M * heads, 64].  rope may be NULL then
+   * (normalisation only).  What the backward needs is written beside the output:
+   *   aux     [2][M][rope_width] bf16: the un-normalised q, then k
+   *   qk_rstd [2][M * heads] float32, qk_mean likewise (LayerNorm only). */
+  const float* qk_norm_weight;  /* [2][64] float32: q_norm.weight then k_norm.weight, or NULL (no normalisation) */
+  const float* qk_norm_bias;    /* [2][64] float32 or NULL */
+  float* qk_rstd;
+  float* qk_mean;
+  float qk_eps;
+  int32_t qk_layernorm;
 } VitkGemm;
 
 size_t vitk_gemm_workspace_bytes(const VitkGemm* g);

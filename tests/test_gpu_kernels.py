@@ -343,6 +343,52 @@ def test_gemm_rope_epilogue_equals_projection_then_rotation(shape, algo, emu):
     assert not torch.equal(got, plain)
 
 
+@pytest.mark.parametrize("with_rope", [False, True])
+@pytest.mark.parametrize("layernorm", [False, True])
+@pytest.mark.parametrize("shape", [(3, 37, 2, 5), (40, 197, 6, 1), (256, 272, 12, 16)])
+def test_gemm_epilogue_with_per_head_qk_normalisation(shape, layernorm, with_rope):
+    """The QKV projection with q and k normalised per head (and then rotated) in its epilogue is bit-identical to the
+    plain projection, vitk_norm_fwd on the heads copied out as [M * H, 64] rows, and vitk_rope_qk; the un-normalised heads
+    and the row statistics it leaves for the backward pass equal what that path saves."""
+    B, S, H, prefix = shape
+    if B * S > 10000 and not (layernorm and with_rope):
+        pytest.skip("the full-size shape runs once")
+    Dh, D, M = 64, 64 * H, B * S
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(M, D, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(DEV, torch.bfloat16)
+    bias = torch.randn(3 * D, generator=g).to(DEV, torch.bfloat16)
+    nw = (1 + 0.2 * torch.randn(2, Dh, generator=g)).to(DEV)
+    nb = (0.1 * torch.randn(2, Dh, generator=g)).to(DEV) if layernorm else None
+    ang = torch.rand(S - prefix, Dh, generator=g) * 6.28
+    table = torch.stack([ang.sin(), ang.cos()]).to(DEV)
+    eps = 1e-5
+    want = torch.empty(M, 3 * D, device=DEV, dtype=torch.bfloat16)
+    K.gemm(x, w, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=want, bias=bias)
+    saved = []
+    for which in range(2):
+        pre = want[:, which * D:(which + 1) * D].contiguous().view(M * H, Dh)
+        nrm, r_, m_ = K.norm_fwd(pre, nw[which].contiguous(), None if nb is None else nb[which].contiguous(), eps, layernorm,
+                                 torch.bfloat16)
+        want[:, which * D:(which + 1) * D].copy_(nrm.view(M, D))
+        saved.append((pre, r_, m_))
+    if with_rope:
+        K.rope_qk_(want, table, B, S, H, Dh, prefix, False, False)
+    got = torch.empty_like(want)
+    pre = torch.empty(2, M, D, device=DEV, dtype=torch.bfloat16)
+    rstd = torch.empty(2, M * H, device=DEV)
+    mean = torch.empty(2, M * H, device=DEV) if layernorm else None
+    K.gemm(x, w, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=got, bias=bias, epilogue=L.EPI_ROPE,
+           rope=table if with_rope else None, rope_width=D, seq=S, prefix=prefix if with_rope else 0, aux=pre,
+           qk_norm=dict(weight=nw.contiguous(), bias=nb, rstd=rstd, mean=mean, eps=eps, layernorm=layernorm))
+    for which in range(2):
+        assert torch.equal(pre[which].view(M * H, Dh), saved[which][0]), which
+        assert torch.equal(rstd[which], saved[which][1]), which
+        if layernorm:
+            assert torch.equal(mean[which], saved[which][2]), which
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("emu", [False, True])
 @pytest.mark.parametrize("S,prefix", [(64, 0), (197, 1), (272, 16), (600, 24)])
 def test_attention_backward_with_fused_inverse_rotation(S, prefix, emu):

@@ -37,6 +37,8 @@ class VitkGemm(C.Structure):
         ("act", C.c_int32), ("use_limit", C.c_int32), ("use_extra", C.c_int32), ("limit", C.c_float), ("extra_bias", C.c_float),
         ("a_colsum", C.c_void_p), ("dynamic_tiles", C.c_int32), ("pos_f32", C.c_int32),
         ("rope", C.c_void_p), ("rope_width", C.c_int64), ("rope_emulate_bf16", C.c_int32),
+        ("qk_norm_weight", C.c_void_p), ("qk_norm_bias", C.c_void_p), ("qk_rstd", C.c_void_p), ("qk_mean", C.c_void_p),
+        ("qk_eps", C.c_float), ("qk_layernorm", C.c_int32),
     ]
 
 

@@ -32,6 +32,19 @@ template <class T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
 __device__ __forceinline__ float round_bf16(float v) { return (float)((bf16)v); }
+// One output element of a row normalisation, y = (x - mean) * rstd * w (+ b), with the products and the sum rounded one
+// by one, and the sum of squares of a 4-element group as an fma chain: the row kernels and the fused per-head
+// normalisation of the QKV projection's epilogue use these, in the same order, so that both produce the same bits.
+__device__ __forceinline__ float norm_apply(float c, float rstd, float w, float b, bool has_b) {
+  const float t = __fmul_rn(__fmul_rn(c, rstd), w);
+  return has_b ? __fadd_rn(t, b) : t;
+}
+__device__ __forceinline__ float sumsq4(float s, float c0, float c1, float c2, float c3) {
+  s = __fmaf_rn(c0, c0, s);
+  s = __fmaf_rn(c1, c1, s);
+  s = __fmaf_rn(c2, c2, s);
+  return __fmaf_rn(c3, c3, s);
+}
 // One output element of apply_rope (vit/rope.py:148-163), x * cos + rotate_half(x) * sin, the way eager elementwise ops
 // compute it: two rounded products and a rounded sum, never contracted into an fma, so that every kernel that rotates
 // (the stand-alone pass, the projection epilogue, the attention backward stores) produces the same bits.

@@ -52,8 +52,7 @@ __global__ __launch_bounds__(256) void norm_fwd_k(const TX* __restrict__ x, cons
     float s2 = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
       Vec4<TX> v; v.load(xr + d);
-#pragma unroll
-      for (int i = 0; i < 4; i++) { float c = v.v[i] - mean; s2 += c * c; }
+      s2 = sumsq4(s2, v.v[0] - mean, v.v[1] - mean, v.v[2] - mean, v.v[3] - mean);
     }
     const float var = wave_sum(s2) * invD;
     const float rstd = rsqrtf(var + eps);
@@ -69,10 +68,10 @@ __global__ __launch_bounds__(256) void norm_fwd_k(const TX* __restrict__ x, cons
       if (LN && b) {
         Vec4<TW> bv; bv.load(b + d);
 #pragma unroll
-        for (int i = 0; i < 4; i++) o.v[i] = (v.v[i] - mean) * rstd * wv.v[i] + bv.v[i];
+        for (int i = 0; i < 4; i++) o.v[i] = norm_apply(v.v[i] - mean, rstd, wv.v[i], bv.v[i], true);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) o.v[i] = (v.v[i] - mean) * rstd * wv.v[i];
+        for (int i = 0; i < 4; i++) o.v[i] = norm_apply(v.v[i] - mean, rstd, wv.v[i], 0.f, false);
       }
       o.store(yr + d);
     }

@@ -675,6 +675,8 @@ static Epi make_epi(const VitkGemm* g) {
   e.asum = g->a_colsum; e.asum_partial = nullptr; e.m_off = 0;
   e.pos_f32 = g->pos_f32 || g->in_dtype == VITK_F32;
   e.rope = g->rope; e.rope_width = g->rope_width; e.rope_emu = g->rope_emulate_bf16;
+  e.qk_w = g->qk_norm_weight; e.qk_b = g->qk_norm_bias; e.qk_rstd = g->qk_rstd; e.qk_mean = g->qk_mean;
+  e.qk_eps = g->qk_eps; e.qk_ln = g->qk_layernorm; e.rows_total = g->M;
   return e;
 }
 
@@ -807,9 +809,10 @@ static int launch_mfma_cut(const VitkGemm* g, const Epi& e, int64_t m1, hipStrea
     b.out = (char*)g->out + (size_t)m1 * g->ldo * so;
     if (g->res) b.res = (const char*)g->res + (size_t)m1 * g->ldo * so;
   }
-  if (g->aux) b.aux = (char*)g->aux + (size_t)m1 * g->N * si;
+  if (g->aux && g->epilogue != VITK_EPI_ROPE) b.aux = (char*)g->aux + (size_t)m1 * g->N * si;   // ROPE: indexed by global row
   Epi ea = make_epi(&a), eb = make_epi(&b);
   eb.m_off = m1;
+  ea.rows_total = eb.rows_total = g->M;
   (void)e;
   launch_mfma<TO>(&a, ea, st);
   launch_mfma<TO>(&b, eb, st);
@@ -859,11 +862,16 @@ extern "C" int vitk_gemm(const VitkGemm* g, void* stream) {
     VITK_REQUIRE(g->tokens > 0 && g->M % g->tokens == 0 && g->seq >= g->prefix + g->tokens,
                  "gemm: PATCH epilogue needs tokens | M and seq >= prefix + tokens");
   if (g->epilogue == VITK_EPI_ROPE)
-    VITK_REQUIRE(g->rope && g->rope_width > 0 && g->rope_width % 64 == 0 && g->N % 64 == 0 && g->seq > 0 && g->prefix >= 0 &&
+    VITK_REQUIRE((g->rope || g->qk_norm_weight) && g->rope_width > 0 && g->rope_width % 64 == 0 && g->N % 64 == 0 && g->seq > 0 && g->prefix >= 0 &&
                      g->prefix < g->seq && g->in_dtype == VITK_BF16 && g->out_dtype == VITK_BF16 && !g->trans_a && !g->trans_b &&
                      ((uintptr_t)g->rope & 15) == 0,
                  "gemm: ROPE epilogue needs a table, bf16 operands and output, row-major A and nn.Linear-layout B, sections "
                  "of whole 64-column heads and 0 <= prefix < seq");
+  if (g->qk_norm_weight)
+    VITK_REQUIRE(g->epilogue == VITK_EPI_ROPE && g->aux && g->qk_rstd && (!g->qk_layernorm || g->qk_mean) &&
+                     ((uintptr_t)g->qk_norm_weight & 15) == 0 && ((uintptr_t)g->qk_norm_bias & 15) == 0,
+                 "gemm: per-head q/k normalisation needs the ROPE epilogue, aux for the un-normalised q and k, and rstd "
+                 "(and mean for LayerNorm) outputs");
   if (g->pos_f32) VITK_REQUIRE(g->epilogue == VITK_EPI_PATCH && g->out_dtype == VITK_F32, "gemm: pos_f32 needs the PATCH epilogue and a float32 output");
   if (g->a_colsum) VITK_REQUIRE(g->trans_a && g->epilogue == VITK_EPI_STORE, "gemm: a_colsum needs trans_a = 1 and the STORE epilogue");
   if (g->M == 0) return 0;

@@ -24,6 +24,15 @@ struct Epi {
   const float* rope;     // ROPE: [2, seq - prefix, 64] sin then cos
   int64_t rope_width;    // ROPE: columns per section (q | k | v); sections 0 and 1 are rotated, heads of 64 columns
   int rope_emu;          // ROPE: round each product to bf16 before the sum (a bf16 table in the reference)
+  // ROPE mode, per-head normalisation of q and k before the rotation (vit/attention.py:25-41): weights [2][64] (q then
+  // k), biases [2][64] or null, rstd / mean [2][rows_total * heads], and aux = the un-normalised q and k [2][rows_total][width]
+  const float* qk_w;
+  const float* qk_b;
+  float* qk_rstd;
+  float* qk_mean;        // LayerNorm only
+  float qk_eps;
+  int qk_ln;
+  int64_t rows_total;    // rows of the whole problem (a launch on the rows after a cut sees fewer)
 };
 
 // sum of a fragment's 8 bf16 values added to s (4 x v_dot2c_f32_bf16 against ones)
@@ -551,16 +560,56 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
         else {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
-          if (MODE == EPI_ROPE) {
-            // rotate_half on the q and k sections of the rows behind the prefix (vit/rope.py:148-163): the linear's output
-            // as bf16 holds it, then  o[d] = x[d] cos[d] - x[d + 32] sin[d]  (d < 32),  o[d] = x[d] cos[d] + x[d - 32] sin[d]
+          if (MODE == EPI_ROPE && ncol < 2 * e.rope_width) {
+            // q and k sections of the fused QKV projection: x = the linear's output as bf16 holds it; then the per-head
+            // normalisation (optional), then rotate_half on the rows behind the prefix (optional).  The 8 lanes that share
+            // a row hold one head; a lane also reads its rotation partner's 8 columns (the other half of the head).
+            float u[8];
+            *(float4*)u = *(const float4*)(stg + row * STG_LD + 8 * (cv ^ 4));
+            *(float4*)(u + 4) = *(const float4*)(stg + row * STG_LD + 8 * (cv ^ 4) + 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              v[j] = round_as<bf16>(v[j]);
+              u[j] = round_as<bf16>(u[j] + cols.wb1[j]);
+            }
+            if (e.qk_w) {
+              const int sec = ncol >= e.rope_width;                       // 0: q, 1: k
+              const int64_t mg = m + e.m_off;
+              store8((bf16*)e.aux + ((int64_t)sec * e.rows_total + mg) * e.rope_width + (ncol - sec * e.rope_width), v);
+              // row statistics in the order of the row kernel (norm_fwd_k: 4 columns per lane, butterfly 8, 4, 2, 1 over
+              // its 16 lanes): this lane carries that kernel's lanes 2 cv and 2 cv + 1 as two partial sums
+              float mean = 0.f;
+              if (e.qk_ln) {
+                float p0 = (v[0] + v[1]) + (v[2] + v[3]), p1 = (v[4] + v[5]) + (v[6] + v[7]);
+#pragma unroll
+                for (int o = 4; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o, 64); p1 += __shfl_xor(p1, o, 64); }
+                mean = (p0 + p1) * (1.f / 64.f);
+              }
+              float q0 = sumsq4(0.f, v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean);
+              float q1 = sumsq4(0.f, v[4] - mean, v[5] - mean, v[6] - mean, v[7] - mean);
+#pragma unroll
+              for (int o = 4; o > 0; o >>= 1) { q0 += __shfl_xor(q0, o, 64); q1 += __shfl_xor(q1, o, 64); }
+              const float rstd = rsqrtf((q0 + q1) * (1.f / 64.f) + e.qk_eps);
+              if (cv == 0) {
+                const int64_t hrow = mg * (e.rope_width >> 6) + ((ncol - sec * e.rope_width) >> 6);
+                const int64_t per = e.rows_total * (e.rope_width >> 6);
+                e.qk_rstd[sec * per + hrow] = rstd;
+                if (e.qk_ln) e.qk_mean[sec * per + hrow] = mean;
+              }
+              const float* wq = e.qk_w + sec * 64;
+              const float* bq = e.qk_b ? e.qk_b + sec * 64 : nullptr;
+#pragma unroll
+              for (int j = 0; j < 8; j++) {
+                const int d = 8 * cv + j, dp = d ^ 32;
+                v[j] = round_as<bf16>(norm_apply(v[j] - mean, rstd, wq[d], bq ? bq[d] : 0.f, bq != nullptr));
+                u[j] = round_as<bf16>(norm_apply(u[j] - mean, rstd, wq[dp], bq ? bq[dp] : 0.f, bq != nullptr));
+              }
+            }
+            // rotate_half (vit/rope.py:148-163):  o[d] = x[d] cos[d] - x[d + 32] sin[d]  (d < 32),  x[d] cos[d] + x[d - 32] sin[d]
             int tok = rope_t0 + row;              // index of the row inside its sample: one division per slab
             while (tok >= (int)e.seq) tok -= (int)e.seq;
             tok -= (int)e.prefix;
-            if (tok >= 0 && ncol < 2 * e.rope_width) {
-              float u[8];
-              *(float4*)u = *(const float4*)(stg + row * STG_LD + 8 * (cv ^ 4));
-              *(float4*)(u + 4) = *(const float4*)(stg + row * STG_LD + 8 * (cv ^ 4) + 4);
+            if (e.rope && tok >= 0) {
               const float* sn = e.rope + tok * 64 + 8 * cv;
               const float* cs = sn + (e.seq - e.prefix) * 64;
               float sv[8], cw[8];
@@ -570,10 +619,7 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
               *(float4*)(cw + 4) = *(const float4*)(cs + 4);
               const float sign = (cv & 4) ? 1.f : -1.f;
 #pragma unroll
-              for (int j = 0; j < 8; j++) {
-                const float x = round_as<bf16>(v[j]), y = sign * round_as<bf16>(u[j] + cols.wb1[j]);
-                v[j] = rope_mix(x, cw[j], y, sv[j], e.rope_emu);
-              }
+              for (int j = 0; j < 8; j++) v[j] = rope_mix(v[j], cw[j], sign * u[j], sv[j], e.rope_emu);
             }
           }
           store8((bf16*)e.out + m * e.ldo + ncol, v);

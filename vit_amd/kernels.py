@@ -112,7 +112,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
          tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None,
          tag: str = "", act: int = 0, limit: Optional[float] = None, extra: Optional[float] = None,
          a_colsum: Optional[Tensor] = None, rope: Optional[Tensor] = None, rope_width: int = 0,
-         rope_emulate_bf16: bool = False) -> Tensor:
+         rope_emulate_bf16: bool = False, qk_norm: Optional[dict] = None) -> Tensor:
     """``a_colsum`` ([M], dtype of out; trans_a products only) receives sum_k A[k, m] from the same pass.
     ``rope`` (EPI_ROPE): fp32 table [2, seq - prefix, 64]; sections of ``rope_width`` columns, the first two rotated."""
     lib = L.load()
@@ -121,6 +121,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     assert a.dtype == b.dtype
     for t in (bias, aux):
         assert t is None or (t.dtype == a.dtype and t.is_contiguous())
+    assert rope is None or seq > prefix >= 0
     # a position table wider than the operands (a learned fp32 table under autocast) is added unrounded to an fp32 output
     pos_f32 = pos is not None and pos.dtype == torch.float32 and a.dtype != torch.float32
     assert pos is None or (pos.is_contiguous() and (pos.dtype == a.dtype or (pos_f32 and out.dtype == torch.float32)))
@@ -150,6 +151,13 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
         L.require_gpu(rope)
         assert rope.dtype == torch.float32 and rope.is_contiguous() and tuple(rope.shape) == (2, seq - prefix, 64)
     g.rope, g.rope_width, g.rope_emulate_bf16 = L.ptr(rope), rope_width, int(rope_emulate_bf16)
+    if qk_norm is not None:   # {"weight": [2, 64] f32, "bias": [2, 64] f32 | None, "rstd", "mean" | None, "eps", "layernorm"}
+        for t in (qk_norm["weight"], qk_norm["bias"], qk_norm["rstd"], qk_norm["mean"]):
+            assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+        assert aux is not None and aux.numel() == 2 * M * rope_width
+        g.qk_norm_weight, g.qk_norm_bias = L.ptr(qk_norm["weight"]), L.ptr(qk_norm["bias"])
+        g.qk_rstd, g.qk_mean = L.ptr(qk_norm["rstd"]), L.ptr(qk_norm["mean"])
+        g.qk_eps, g.qk_layernorm = float(qk_norm["eps"]), int(qk_norm["layernorm"])
     g.workspace, g.workspace_bytes = None, 0
     need = lib.vitk_gemm_workspace_bytes(C.byref(g))
     if need:
@@ -172,6 +180,13 @@ def can_fuse_rope(dtype: torch.dtype, Dh: int, table: Optional[Tensor]) -> bool:
     if os.environ.get("VITK_NO_ROPE_FUSE"):   # measurements: the rotation as a pass of its own
         return False
     return table is not None and table.dim() == 3 and dtype == torch.bfloat16 and _ALGO != 1 and Dh == 64
+
+
+def can_fuse_qk_norm(dtype: torch.dtype, Dh: int) -> bool:
+    """The QKV GEMM can normalise the heads of q and k in its epilogue (bf16 operands, head_dim 64)."""
+    if os.environ.get("VITK_NO_ROPE_FUSE"):
+        return False
+    return dtype == torch.bfloat16 and _ALGO != 1 and Dh == 64
 
 
 def can_fuse_activation(dtype: torch.dtype, D: int, F: int) -> bool:
@@ -211,7 +226,7 @@ def attn_fwd(qkv: Tensor, B: int, S: int, H: int, Dh: int, scale: float, drop_p:
 
 def attn_bwd(qkv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, S: int, H: int, Dh: int, scale: float,
              drop_p: float = 0.0, seed: int = 0, algo: Optional[int] = None, rope: Optional[Tensor] = None,
-             rope_emulate_bf16: bool = False) -> Tensor:
+             rope_emulate_bf16: bool = False, qk_norm: Optional[dict] = None) -> Tensor:
     """Returns dqkv in the packed layout of qkv.  ``rope`` (fp32 [2, S - prefix, 64]): q and k were rotated with this
     table before the attention; dq and dk come back through the transposed rotation."""
     lib = L.load()

@@ -321,6 +321,22 @@ def _rope_table(rope: Optional[Tensor], keep_idx: Optional[Tensor], B: int, Bk: 
     return table, emu
 
 
+_QK_PARAMS: dict = {}   # id(q_norm.weight) -> (key of all four parameters, weakref, stacked fp32 weights, stacked fp32 biases)
+
+
+def _qk_norm_params(qw: Tensor, qb: Optional[Tensor], kw: Tensor, kb: Optional[Tensor]):
+    """[2, Dh] fp32 weights (and biases) of q_norm and k_norm for the projection epilogue, rebuilt when any of them changes."""
+    key = tuple(None if t is None else (id(t), t._version, t.data_ptr()) for t in (qw, qb, kw, kb))
+    ent = _QK_PARAMS.get(id(qw))
+    if ent is not None and ent[0] == key and ent[1]() is qw:
+        return ent[2], ent[3]
+    w2 = torch.stack([qw.detach().float(), kw.detach().float()]).contiguous()
+    b2 = None if qb is None or kb is None else torch.stack([qb.detach().float(), kb.detach().float()]).contiguous()
+    ident = id(qw)
+    _QK_PARAMS[ident] = (key, weakref.ref(qw, lambda _r, ident=ident: _QK_PARAMS.pop(ident, None)), w2, b2)
+    return w2, b2
+
+
 class AttentionSublayerFn(torch.autograd.Function):
     """x -> x (+) alpha * gamma * dropout(out_proj(SDPA(rope(qkv_proj(norm(x))))))   (vit/attention.py:163-215)."""
 
@@ -348,17 +364,32 @@ class AttentionSublayerFn(torch.autograd.Function):
         table, emu = _rope_table(rope, keep_idx, B, Bk, tc)
         # head_dim 64, one table for all samples: q and k are rotated in the projection's epilogue and their gradients
         # un-rotated in the attention backward's stores; otherwise the rotation is a pass of its own over q and k
-        fuse_rope = qn_w is None and K.can_fuse_rope(tc, Dh, table)
-        if fuse_rope:
+        fuse_rope = K.can_fuse_rope(tc, Dh, table)
+        fuse_norm = qn_w is not None and K.can_fuse_qk_norm(tc, Dh)
+        qk_saved = (None,) * 6
+        if fuse_norm:
+            # per-head q/k normalisation (vit/attention.py:25-41, :95-105) in the projection's epilogue, before the rotation;
+            # the un-normalised heads and the row statistics are written beside qkv for the backward pass
+            qk_ln = opt["qk_layernorm"]
+            w2, b2 = _qk_norm_params(qn_w, qn_b if qk_ln else None, kn_w, kn_b if qk_ln else None)
+            pre = torch.empty((2, M, D), dtype=tc, device=x.device)
+            stat_r = torch.empty((2, M * H), dtype=torch.float32, device=x.device)
+            stat_m = torch.empty((2, M * H), dtype=torch.float32, device=x.device) if qk_ln else None
+            K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv", epilogue=L.EPI_ROPE,
+                   rope=table if fuse_rope else None, rope_width=D, rope_emulate_bf16=emu, seq=S,
+                   prefix=S - table.shape[-2] if fuse_rope else 0, aux=pre,
+                   qk_norm=dict(weight=w2, bias=b2, rstd=stat_r, mean=stat_m, eps=opt["qk_eps"], layernorm=qk_ln))
+            qk_saved = [pre[0].view(M * H, Dh), stat_r[0], None if stat_m is None else stat_m[0],
+                        pre[1].view(M * H, Dh), stat_r[1], None if stat_m is None else stat_m[1]]
+        elif fuse_rope and qn_w is None:
             K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv", epilogue=L.EPI_ROPE,
                    rope=table, rope_width=D, rope_emulate_bf16=emu, seq=S, prefix=S - table.shape[-2])
         else:
+            fuse_rope = False
             K.gemm(xn, wq, trans_a=False, trans_b=False, M=M, N=3 * D, K=D, out=qkv, bias=bq, tag="qkv")
-        # per-head q/k normalisation over Dh, before RoPE (vit/attention.py:25-41, :95-105).  The heads of q (and of k)
-        # are copied out as a contiguous [M*H, Dh] matrix, which is what the row-norm kernels take and what their
-        # backward needs; the normalised rows go back into the packed buffer.
-        qk_saved = (None,) * 6
-        if qn_w is not None:
+        # otherwise the heads of q (and of k) are copied out as a contiguous [M*H, Dh] matrix, which is what the row-norm
+        # kernels take and what their backward needs; the normalised rows go back into the packed buffer.
+        if qn_w is not None and not fuse_norm:
             qk_saved = []
             for which, (w_, b_) in enumerate(((qn_w, qn_b), (kn_w, kn_b))):
                 pre = qkv[:, which * D:(which + 1) * D].contiguous().view(M * H, Dh)

@@ -363,28 +363,37 @@ __device__ __forceinline__ void stage_store(const uint4 (&r)[NCH], char* s, int 
   }
 }
 
+// Both fragment readers form their address as  tile + (a term of the lane alone) + (a compile-time constant): with r0 a
+// multiple of 32 the swizzle of a row depends on the lane only and touches the two low bits of the chunk index, so one
+// tile needs two lane terms per reader (k-step parity / row half) and everything else sits in the instruction's offset
+// field.  Spelled out this way the loops hold a handful of address registers instead of one per fragment.
 // row-wise operand fragment: element j = tile[r0 + (lane&31)][ks*16 + 8*(lane>>5) + j]   (r0 a multiple of 32)
 template <int STRIDE, int SWZ>
 __device__ __forceinline__ bf16x8 frag_rows(const char* s, int r0, int ks, int lane) {
-  const int row = r0 + (lane & 31);
-  int chunk = ks * 2 + (lane >> 5);
-  chunk ^= swz_of<SWZ>(row);
-  return *(const bf16x8*)(s + row * STRIDE + chunk * 16);
+  const int rl = lane & 31, hi = lane >> 5;
+  const int w = swz_of<SWZ>(rl);
+  const int low = (((ks * 2) & 3) | hi) ^ w;          // chunk index, low two bits: one lane term per parity of ks
+  const int lane_off = rl * STRIDE + low * 16;
+  const int imm = r0 * STRIDE + ((ks * 2) & ~3) * 16;
+  return *(const bf16x8*)(s + lane_off + imm);
 }
 // column-wise operand fragment for a product whose other operand is an accumulator tile converted in
-// place: element j = tile[r0 + 16*s2 + 8*(j>>2) + 4*(lane>>5) + (j&3)][c0 + (lane&31)]
+// place: element j = tile[r0 + 16*s2 + 8*(j>>2) + 4*(lane>>5) + (j&3)][c0 + (lane&31)]   (r0, c0 multiples of 32)
 template <int STRIDE, int SWZ>
 __device__ __forceinline__ bf16x8 frag_cols(const char* s, int r0, int s2, int c0, int lane) {
-  const int row = r0 + 16 * s2 + 4 * (lane >> 5) + ((lane & 15) >> 2);
-  const int col = c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const int chunk = col >> 3, sub = (col & 7) * 2;
-  const int c_lo = chunk ^ swz_of<SWZ>(row);
-  const int c_hi = chunk ^ swz_of<SWZ>(row + 8);
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + row * STRIDE + c_lo * 16 + sub));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + (row + 8) * STRIDE + c_hi * 16 + sub));
+  const int hi = lane >> 5, l3 = lane & 3;
+  const int rowl = 4 * hi + ((lane & 15) >> 2);       // the lane's row inside a 16-row group; its partner row is 8 below
+  const int cl = 2 * ((lane >> 4) & 1) + (l3 >> 1);   // the lane's chunk inside a 32-column group
+  const int sub = (l3 & 1) * 8;
+  const int w_lo = SWZ == 1 ? hi : 0, w_hi = SWZ == 1 ? (hi | 2) : 0;   // swz_of(row), swz_of(row + 8)
+  const int lane_lo = rowl * STRIDE + (cl ^ w_lo) * 16 + sub;
+  const int lane_hi = (rowl + 8) * STRIDE + (cl ^ w_hi) * 16 + sub;
+  const int imm = (r0 + 16 * s2) * STRIDE + (c0 >> 3) * 16;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + lane_lo + imm));
+  bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + lane_hi + imm));
   bf16x8 f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  f[4] = hi4[0]; f[5] = hi4[1]; f[6] = hi4[2]; f[7] = hi4[3];
   return f;
 }
 // accumulator registers 8*s2 .. 8*s2+7 as the B operand of the next product (k-step s2)
@@ -598,7 +607,7 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
 }
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP p) {
 #ifdef EXP_STAMP   // diagnostic build: cycle stamps of wave 0 per block go to the lse buffer (tools/stamp_attn.py reads them)
   const uint64_t st0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -725,7 +734,7 @@ __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const ch
 }
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, (DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int KS = Strides<DHP>::COLS, VS = Strides<DHP>::ROWS;  // K is read both ways (swizzled), V row-wise only
   constexpr int TILE = 64 * KS + 64 * VS;
@@ -861,8 +870,14 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
   }
 }
 
+// AHEAD = query tiles in flight from global memory to LDS.  Two (one being written to LDS while the next is on its way)
+// keep a short sequence's few tiles fed; one needs half the staging registers, which is what lets the head_dim 65-96
+// instance keep two waves per SIMD without spilling, and a tile's arithmetic there is long enough to cover a load.
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_dkdv_k(AttnP p) {
+constexpr int dkdv_ahead() { return (DHP > 64 && DHP <= 96 && !DROP && NW == 4) ? 1 : 2; }
+template <int DHP, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64, (((DHP <= 64 || (DHP <= 96 && NW == 4)) && !DROP) ? 2 : 1)) void attn_dkdv_k(AttnP p) {
+  constexpr int AHEAD = dkdv_ahead<DHP, NW, DROP>();
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int QS = Strides<DHP>::COLS;   // Q and dO tiles are read both ways (swizzled)
   constexpr int TILE = 2 * 64 * QS + 512;  // Q, dO, then -lse*log2e [64] and delta [64]
@@ -882,7 +897,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_
   const TileSrc<NCH> qsrc = make_tilesrc<DHP, NT, NCH>(qp, p.q_ss, S, Dh, tid);
   const TileSrc<NCH> gsrc = make_tilesrc<DHP, NT, NCH>(gp, p.o_ss, S, Dh, tid);
   const int ntiles = (S + 63) >> 6, nfull = S >> 6;
-  uint4 rqA[NCH], rgA[NCH], rqB[NCH], rgB[NCH];
+  uint4 rqA[NCH], rgA[NCH], rqB[AHEAD == 2 ? NCH : 1], rgB[AHEAD == 2 ? NCH : 1];
   float rlA = 0.f, rlB = 0.f;
   // per-row constants of a query tile: wave 0 fetches -lse*log2e, wave 1 delta (branch-free buffer loads).
   // Rows beyond S get -lse = -inf, which makes their probability exactly 0.
@@ -900,9 +915,11 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_
   stage_load(rqA, qsrc, 0);
   stage_load(rgA, gsrc, 0);
   load_row_consts(rlA, 0);
-  stage_load(rqB, qsrc, 1);
-  stage_load(rgB, gsrc, 1);
-  load_row_consts(rlB, 64);
+  if constexpr (AHEAD == 2) {
+    stage_load(rqB, qsrc, 1);
+    stage_load(rgB, gsrc, 1);
+    load_row_consts(rlB, 64);
+  }
   const float c = p.scale * LOG2E;
   const f32x16 zero = ZERO16;
   f32x16 dkacc[DHP / 32], dvacc[DHP / 32];
@@ -913,23 +930,40 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP) ? 2 : 1)) void attn_
   if (tid < 128) ((float*)(smem + 2 * 64 * QS))[tid] = rlA;
   __syncthreads();
 
-  auto step = [&](int t, uint4 (&nq)[NCH], uint4 (&ng)[NCH], float& nl, uint4 (&fq)[NCH], uint4 (&fg)[NCH], float& fl) {
-    const char* sQ = smem + (t & 1) * TILE;
-    const char* sG = sQ + 64 * QS;
-    const float* sL = (const float*)(sQ + 2 * 64 * QS);
-    stage_load(fq, qsrc, t + 2);
-    stage_load(fg, gsrc, t + 2);
-    load_row_consts(fl, (t + 2) * 64);
-    if (wave_on) dkdv_tile<DHP, 2, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, t * 64, sbase, krow, lane);
-    char* nQ = smem + ((t + 1) & 1) * TILE;
-    stage_store<DHP, NT, NCH, QS, true>(nq, nQ, tid);
-    stage_store<DHP, NT, NCH, QS, true>(ng, nQ + 64 * QS, tid);
-    if (tid < 128) ((float*)(nQ + 2 * 64 * QS))[tid] = nl;
-    __syncthreads();
-  };
-  for (int t = 0; t < nfull; t += 2) {
-    step(t, rqB, rgB, rlB, rqA, rgA, rlA);
-    if (t + 1 < nfull) step(t + 1, rqA, rgA, rlA, rqB, rgB, rlB);
+  if constexpr (AHEAD == 2) {
+    auto step = [&](int t, uint4 (&nq)[NCH], uint4 (&ng)[NCH], float& nl, uint4 (&fq)[NCH], uint4 (&fg)[NCH], float& fl) {
+      const char* sQ = smem + (t & 1) * TILE;
+      const char* sG = sQ + 64 * QS;
+      const float* sL = (const float*)(sQ + 2 * 64 * QS);
+      stage_load(fq, qsrc, t + 2);
+      stage_load(fg, gsrc, t + 2);
+      load_row_consts(fl, (t + 2) * 64);
+      if (wave_on) dkdv_tile<DHP, 2, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, t * 64, sbase, krow, lane);
+      char* nQ = smem + ((t + 1) & 1) * TILE;
+      stage_store<DHP, NT, NCH, QS, true>(nq, nQ, tid);
+      stage_store<DHP, NT, NCH, QS, true>(ng, nQ + 64 * QS, tid);
+      if (tid < 128) ((float*)(nQ + 2 * 64 * QS))[tid] = nl;
+      __syncthreads();
+    };
+    for (int t = 0; t < nfull; t += 2) {
+      step(t, rqB, rgB, rlB, rqA, rgA, rlA);
+      if (t + 1 < nfull) step(t + 1, rqA, rgA, rlA, rqB, rgB, rlB);
+    }
+  } else {
+    for (int t = 0; t < nfull; t++) {   // tile t + 1 travels while tile t is multiplied
+      const char* sQ = smem + (t & 1) * TILE;
+      const char* sG = sQ + 64 * QS;
+      const float* sL = (const float*)(sQ + 2 * 64 * QS);
+      stage_load(rqA, qsrc, t + 1);   // tiles beyond the sequence read as zeros
+      stage_load(rgA, gsrc, t + 1);
+      load_row_consts(rlA, (t + 1) * 64);
+      if (wave_on) dkdv_tile<DHP, 2, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, t * 64, sbase, krow, lane);
+      char* nQ = smem + ((t + 1) & 1) * TILE;
+      stage_store<DHP, NT, NCH, QS, true>(rqA, nQ, tid);
+      stage_store<DHP, NT, NCH, QS, true>(rgA, nQ + 64 * QS, tid);
+      if (tid < 128) ((float*)(nQ + 2 * 64 * QS))[tid] = rlA;
+      __syncthreads();
+    }
   }
   if (nfull < ntiles && wave_on) {
     const char* sQ = smem + (nfull & 1) * TILE;
@@ -998,12 +1032,15 @@ static int attn_validate(const VitkAttn* a, bool bwd) {
   if (bwd) VITK_REQUIRE(a->dout && a->dq && a->dk && a->dv && a->delta, "attn_bwd: null pointer");
   return 0;
 }
-// waves (32 rows each) per workgroup.  Backward: the count in {4, 3, 2} that pads the sequence least.  Forward: 4 waves
-// unless the sequence is short -- its per-wave work is small, so sharing each staged K/V tile among more waves
-// outweighs the idle waves of a padded last block (measured at S = 272: 0.150 ms with 4 waves, 0.178 ms with 3).
+// waves (32 rows each) per workgroup: 4 unless the sequence is short.  The 4-wave instances are the ones tuned for
+// occupancy (three waves per SIMD for head_dim <= 64 forward and dQ, two for the head_dim 65-96 dK/dV kernel), and sharing
+// each staged tile among more waves outweighs the idle waves of a padded last block (measured at S = 272, head_dim 64:
+// forward 0.150 ms with 4 waves, 0.178 ms with 3; backward 0.51 against 0.545; head_dim 80: backward 0.24 against 0.32).
+// At S <= 128 the count in {4, 3, 2} that pads the sequence least.
 static int pick_nw(int64_t S, int64_t Dh, bool fwd) {
   if (const char* f = getenv("VITK_ATTN_NW")) { const int v = atoi(f); if (v >= 2 && v <= 4) return v; }
-  if (Dh > 96 || S >= 2048 || (fwd && S > 128)) return 4;
+  (void)fwd;
+  if (Dh > 96 || S > 128) return 4;
   int best = 4;
   int64_t best_pad = ceil_div(S, 128) * 128 - S;
   for (int nw = 3; nw >= 2; nw--) {

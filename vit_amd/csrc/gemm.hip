@@ -631,7 +631,23 @@ static int pick_splits(const VitkGemm* g) {
   const bool big = use_tile256(g);
   const int64_t tiles = big ? ceil_div(g->M, BM2) * ceil_div(g->N, BN2) : ceil_div(g->M, BM) * ceil_div(g->N, BN);
   const int64_t slots = big ? 256 : 768;       // blocks one round holds: one 256^2 block or three 128^2 blocks per CU
-  if (tiles >= slots || g->K < 2048) return 1;
+  if (g->K < 2048) return 1;
+  if (tiles >= slots) {
+    // More tiles than one round holds: a last round that is mostly empty costs a whole round (288 tiles on 256 CUs take
+    // two).  Row-major-A problems are cut along M instead (ragged_round_cut); for a weight gradient with a long
+    // contraction, splitting K evens the rounds out at the price of the partial sums' traffic.  Model, in microseconds:
+    // rounds x K-steps per tile x 1.65 us per 256^2 K-step, plus 8 bytes per partial element at 5 TB/s.
+    if (!big || !g->trans_a || g->K < 8192) return 1;
+    auto cost = [&](int64_t sp) {
+      const double gemm = (double)ceil_div(tiles * sp, slots) * (double)ceil_div(ceil_div(g->K, sp), BK) * 1.65;
+      return gemm + (sp > 1 ? (double)sp * (double)g->M * (double)g->N * 8.0 / 5e6 : 0.0);
+    };
+    int64_t best = 1;
+    double best_cost = cost(1) * 0.9;   // a split has to win by 10 %
+    for (int64_t sp = 2; sp <= 16; sp++)
+      if (cost(sp) < best_cost) { best = sp; best_cost = cost(sp); }
+    return (int)best;
+  }
   // the fewest splits (least partial traffic) that fill whole rounds to at least 94 %, at most two rounds
   const int64_t smax = g->K / 1024 < 64 ? g->K / 1024 : 64;
   int64_t best = 1;

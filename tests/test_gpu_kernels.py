@@ -112,6 +112,25 @@ def test_mfma_gemm_splitk_wgrad_shape():
         close(out, ref, 1e-2 if od == torch.bfloat16 else 0, 1e-2 if od == torch.bfloat16 else 0)
 
 
+def test_gemm_weight_gradient_with_a_ragged_second_round_splits_k():
+    """288 tiles of 256x256 (ViT-g/14's fc1 weight gradient has 48 x 6) on 256 CUs: the second round would be 1/8 full,
+    so the automatic path splits the long contraction instead.  Integer operands keep every partial sum exact; the
+    fused bias-gradient row sums travel through the same partial buffers."""
+    M, N, Kd = 256 * 48, 256 * 6 - 128, 8192
+    g = torch.Generator().manual_seed(48)
+    A = torch.randint(-2, 3, (Kd, M), generator=g).to(torch.bfloat16)
+    B = torch.randint(-2, 3, (Kd, N), generator=g).to(torch.bfloat16)
+    a, b = A.to(DEV), B.to(DEV)
+    ref = a.float().t() @ b.float()
+    ref_sum = a.float().sum(0)
+    for od in (torch.float32, torch.bfloat16):
+        out = torch.empty(M, N, device=DEV, dtype=od)
+        sums = torch.full((M,), float("nan"), device=DEV, dtype=od)
+        K.gemm(a, b, trans_a=True, trans_b=True, M=M, N=N, K=Kd, out=out, a_colsum=sums, algo=0)
+        assert torch.equal(out.float(), ref.to(od).float()), od
+        assert torch.equal(sums.float(), ref_sum.to(od).float()), od
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_random_bias_and_tolerance(dtype):
     M, N, Kd = 520, 384, 256

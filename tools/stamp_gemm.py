@@ -1,5 +1,5 @@
 """Reads the per-segment cycle sums an EXP_STAMP build of gemm_mfma256d_k keeps (diagnostics only):
-VITK_LIB=exp/libvitk_stamp.so python tools/stamp_gemm.py [store|glu|dglu|res]"""
+VITK_LIB=exp/libvitk_stamp.so python tools/stamp_gemm.py [store|glu|dglu|res|out|fc2]"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -16,6 +16,11 @@ if mode == "glu":
 elif mode == "store":
     w, out = rnd(2 * F, D), torch.empty(M, 2 * F, device="cuda", dtype=torch.bfloat16)
     run = lambda: K.gemm(a, w, trans_a=False, trans_b=False, M=M, N=2 * F, K=D, out=out, algo=5)
+elif mode in ("out", "fc2"):   # narrow outputs: N = D, K = D or F, plain bf16 store
+    kk = D if mode == "out" else F
+    a = rnd(M, kk)
+    w, out = rnd(D, kk), torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    run = lambda: K.gemm(a, w, trans_a=False, trans_b=False, M=M, N=D, K=kk, out=out, algo=5)
 elif mode == "res":
     a = rnd(M, F)
     w, out, res = rnd(D, F), torch.empty(M, D, device="cuda"), torch.randn(M, D, device="cuda")

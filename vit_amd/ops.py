@@ -52,11 +52,18 @@ def next_seed(device: torch.device) -> int:
     return (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
 
 
+_ARANGE: dict = {}   # (S, device) -> arange(S) as a [1, S] int64 row
+
+
 def token_rows(keep_idx: Optional[Tensor], S: int) -> Optional[Tensor]:
     """Row numbers in the flattened [B*S, D] stream of the samples selected by ``keep_idx``."""
     if keep_idx is None:
         return None
-    return (keep_idx.to(torch.int64)[:, None] * S + torch.arange(S, device=keep_idx.device)[None, :]).reshape(-1).contiguous()
+    key = (S, keep_idx.device)
+    ar = _ARANGE.get(key)
+    if ar is None:
+        ar = _ARANGE[key] = torch.arange(S, device=keep_idx.device, dtype=torch.int64)[None, :]
+    return torch.add(ar, keep_idx.to(torch.int64)[:, None], alpha=S).reshape(-1)   # one launch: keep_idx * S + arange(S)
 
 
 def _cast(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
@@ -234,8 +241,29 @@ def _residual_dtype(x: Tensor, gamma: Optional[Tensor], tc: torch.dtype) -> torc
     return torch.promote_types(t, gamma.dtype) if gamma is not None else t
 
 
+def _dropped_samples(keep_idx: Optional[Tensor]) -> Optional[Tensor]:
+    """The complement of a drop-path subset, when the code that drew the subset attached it (vit_amd/transformer.py)."""
+    return getattr(keep_idx, "_vitk_dropped", None) if keep_idx is not None else None
+
+
+def _passthrough(src2: Tensor, dropped: Optional[Tensor], rows_per_sample: int) -> tuple:
+    """(out, res) for a kernel that writes out[r] = res[r] + ... on the rows of the kept samples only: ``out`` already
+    holds ``src2``'s rows of the dropped samples.  With the list of dropped samples only their rows are copied (the
+    kernel reads the kept rows from src2 and writes every one of them); without it the whole stream is cloned and
+    updated in place."""
+    if dropped is None or src2.shape[0] % rows_per_sample:
+        out = src2.clone()
+        return out, out
+    out = torch.empty_like(src2)
+    if dropped.numel():
+        width = rows_per_sample * src2.shape[1]
+        out.view(-1, width).index_copy_(0, dropped, src2.view(-1, width).index_select(0, dropped))
+    return out, src2
+
+
 def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, gamma: Optional[Tensor], rows: Optional[Tensor],
-                   alpha: float, drop_p: float, seed: int, want_aux: bool, tag: str = ""):
+                   alpha: float, drop_p: float, seed: int, want_aux: bool, tag: str = "", dropped: Optional[Tensor] = None,
+                   rows_per_sample: int = 1):
     """x_new = x (+ scatter) alpha * gamma * dropout(inp @ w^T + b): the out_proj / fc2 GEMM with its fused epilogue."""
     M, Kin = inp.shape
     N = w_c.shape[0]
@@ -244,8 +272,7 @@ def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, 
         out = torch.empty_like(x2)
         res = x2
     else:
-        out = x2.clone()  # rows of dropped samples pass through; kept rows are updated in place
-        res = out
+        out, res = _passthrough(x2, dropped, rows_per_sample)  # rows of dropped samples pass through
     K.gemm(inp, w_c, trans_a=False, trans_b=False, M=M, N=N, K=Kin, out=out, bias=b_c, epilogue=L.EPI_RESIDUAL, res=res,
            gamma=gamma, row_idx=rows, aux=aux, alpha=alpha, drop_p=drop_p, seed=seed, tag=tag)
     return out, aux
@@ -404,7 +431,8 @@ class AttentionSublayerFn(torch.autograd.Function):
         seed_h = next_seed(x.device) if p_hid > 0 else 0
         g = _cast(gamma, tr)
         if residual:
-            out, aux = _residual_gemm(o, wo, bo, x2, g, rows, opt["alpha"], p_hid, seed_h, want_aux=g is not None, tag="out")
+            out, aux = _residual_gemm(o, wo, bo, x2, g, rows, opt["alpha"], p_hid, seed_h, want_aux=g is not None, tag="out",
+                                      dropped=_dropped_samples(keep_idx), rows_per_sample=S)
             y = out.view(B, S, D)
         else:
             zero = torch.zeros((M, D), dtype=tc, device=x.device)
@@ -414,6 +442,7 @@ class AttentionSublayerFn(torch.autograd.Function):
         ctx.meta = (B, S, D, H, Dh, Bk, tc, tr, p_attn, p_hid, seed_a, seed_h, emu, opt, x.dtype, w_qkv.dtype,
                     norm_b is not None, b_qkv is not None, b_out is not None, qn_b is not None, kn_b is not None, fuse_rope)
         ctx.ptrs = _ptrs(w_qkv, b_qkv, w_out, b_out)
+        ctx.dropped = _dropped_samples(keep_idx)
         return y
 
     @staticmethod
@@ -450,8 +479,7 @@ class AttentionSublayerFn(torch.autograd.Function):
                 dx = torch.empty_like(dnew2)
                 add = dnew2
             else:
-                dx = dnew2.clone()
-                add = dx
+                dx, add = _passthrough(dnew2, ctx.dropped, S)   # dropped samples: the gradient passes through
         else:
             dx = torch.zeros_like(x2) if rows is not None else torch.empty_like(x2)
             add = None
@@ -728,7 +756,8 @@ class MlpSublayerFn(torch.autograd.Function):
         seed_2 = next_seed(x.device) if p_hid > 0 else 0
         g = _cast(gamma, tr)
         if residual:
-            out, aux = _residual_gemm(h, w2c, b2c, x2, g, rows, opt["alpha"], p_hid, seed_2, want_aux=g is not None, tag="fc2")
+            out, aux = _residual_gemm(h, w2c, b2c, x2, g, rows, opt["alpha"], p_hid, seed_2, want_aux=g is not None, tag="fc2",
+                                      dropped=_dropped_samples(keep_idx), rows_per_sample=S)
             y = out.view(shape)
         else:
             zero = torch.zeros((M, D), dtype=tc, device=x.device)
@@ -738,6 +767,7 @@ class MlpSublayerFn(torch.autograd.Function):
         ctx.meta = (shape, D, F, tc, tr, p_hid, seed_1, seed_2, opt, x.dtype, w1.dtype, norm_b is not None, b1 is not None,
                     b2 is not None, fused)
         ctx.ptrs = _ptrs(w1, b1, w2, b2)
+        ctx.dropped, ctx.rows_per_sample = _dropped_samples(keep_idx), S
         return y
 
     @staticmethod
@@ -769,8 +799,7 @@ class MlpSublayerFn(torch.autograd.Function):
                 if rows is None:
                     dx, add = torch.empty_like(dnew2), dnew2
                 else:
-                    dx = dnew2.clone()
-                    add = dx
+                    dx, add = _passthrough(dnew2, ctx.dropped, ctx.rows_per_sample)
             else:
                 dx = torch.zeros_like(x2) if rows is not None else torch.empty_like(x2)
                 add = None

@@ -30,7 +30,10 @@ def _select_keep_indices(x: Tensor, drop_path_rate: float, training: bool):
     keep = drop_path_keep_count(B, drop_path_rate)
     if keep == B:
         return None, 1.0
-    return torch.randperm(B, device=x.device)[:keep], float(B / keep)
+    perm = torch.randperm(B, device=x.device)
+    idx = perm[:keep]
+    idx._vitk_dropped = perm[keep:]   # the samples that pass through unchanged (ops copies only their rows)
+    return idx, float(B / keep)
 
 
 def _select_residual_subset(x: Tensor, drop_path_rate: float, training: bool):

@@ -627,8 +627,11 @@ static bool mfma_ok(const VitkGemm* g) {
 // split the contraction when the output has too few tiles to fill 256 CUs (weight gradients)
 static bool use_tile256(const VitkGemm* g);
 static int pick_splits(const VitkGemm* g) {
-  if (g->epilogue != VITK_EPI_STORE) return 1;
+  // STORE, and the residual epilogue on the 128^2 kernel when it is asked for by name (algo 4: the rows a ragged round
+  // of 256^2 tiles leaves over are few tiles with the whole contraction each; split, they fill the chip, and the
+  // reduction pass applies the epilogue)
   const bool big = use_tile256(g);
+  if (g->epilogue != VITK_EPI_STORE && !(g->epilogue == VITK_EPI_RESIDUAL && g->algo == 4 && !big && !g->trans_a && !g->trans_b)) return 1;
   const int64_t tiles = big ? ceil_div(g->M, BM2) * ceil_div(g->N, BN2) : ceil_div(g->M, BM) * ceil_div(g->N, BN);
   const int64_t slots = big ? 256 : 768;       // blocks one round holds: one 256^2 block or three 128^2 blocks per CU
   if (g->K < 2048) return 1;
@@ -843,7 +846,18 @@ static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st) {
     splits = 1;
   int64_t klen = ceil_div(ceil_div(g->K, splits), BK) * BK;
   splits = (int)ceil_div(g->K, klen);
-  if (g->epilogue == VITK_EPI_RESIDUAL) launch_mfma_one<false, false, VITK_EPI_RESIDUAL, TO>(g, e, 1, klen, nullptr, st);
+  if (g->epilogue == VITK_EPI_RESIDUAL) {
+    if (splits > 1) {   // partial products, then one pass that sums them and applies the epilogue element by element
+      launch_mfma_one<false, false, MODE_PARTIAL, TO>(g, e, splits, klen, (float*)g->workspace, st);
+      const int64_t total = g->M * g->N;
+      int64_t blocks = ceil_div(total, 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL((splitk_reduce_k<VITK_EPI_RESIDUAL, bf16, TO>), dim3((unsigned)blocks), dim3(256), 0, st,
+                         (const float*)g->workspace, g->M, g->N, splits, e);
+    } else {
+      launch_mfma_one<false, false, VITK_EPI_RESIDUAL, TO>(g, e, 1, klen, nullptr, st);
+    }
+  }
   else if (g->epilogue == VITK_EPI_PATCH) launch_mfma_one<false, false, VITK_EPI_PATCH, TO>(g, e, 1, klen, nullptr, st);
   else if (g->epilogue == VITK_EPI_ACT) launch_mfma_one<false, false, VITK_EPI_ACT, TO>(g, e, 1, klen, nullptr, st);
   else if (g->epilogue == VITK_EPI_GLU) launch_mfma_one<false, false, VITK_EPI_GLU, TO>(g, e, 1, klen, nullptr, st);

@@ -572,6 +572,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
       o.v[0] = s.x; o.v[1] = s.y; o.v[2] = s.z; o.v[3] = s.w;
       o.store((TO*)e.out + m * e.ldo + n);
     }
+  } else if (MODE == VITK_EPI_RESIDUAL && N % 4 == 0 && e.ldo % 4 == 0) {   // the MFMA kernels' 4-column epilogue on the summed partials
+    const int64_t nq = N / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < M * nq; q += (int64_t)gridDim.x * 256) {
+      const int64_t m = q / nq, n = (q - m * nq) * 4;
+      EpiPre<VITK_EPI_RESIDUAL, TO> pre;
+      EpiVec<VITK_EPI_RESIDUAL, TO>::prefetch(e, m, n, pre);
+      float4 s4 = *(const float4*)(partial + m * N + n);
+      for (int k = 1; k < splits; k++) {
+        const float4 t = *(const float4*)(partial + (int64_t)k * total + m * N + n);
+        s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
+      }
+      float v[4] = {s4.x, s4.y, s4.z, s4.w}, bias[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f};
+      if (e.bias) {
+        Vec4<bf16> b; b.load((const bf16*)e.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) bias[j] = b.v[j];
+      }
+      if (e.gamma) {
+        Vec4<TO> g; g.load((const TO*)e.gamma + n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) gam[j] = g.v[j];
+      }
+      EpiVec<VITK_EPI_RESIDUAL, TO>::apply(e, m, n, v, bias, gam, pre);
+    }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
       float s = 0.f;

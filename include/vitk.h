@@ -244,6 +244,12 @@ int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_
 int vitk_prefix_fill(const void* cls, int64_t ncls, const void* reg, int64_t nreg, int prefix_dtype, void* out, int out_dtype,
                      int64_t B, int64_t S, int64_t D, void* stream);
 
+/* ---- drop-path pass-through (vit/transformer.py:41-46: `x.flatten(1).index_add(0, keep_indices, ...)` leaves the samples
+ * outside the subset unchanged) ---------------------------------------------------------------------------------------
+ * dst[idx[i]] = src[idx[i]] for i < n, a sample being `sample_bytes` contiguous bytes (a multiple of 16; src and dst 16-byte
+ * aligned).  Called with the dropped samples before the residual epilogue (or the norm backward) writes the kept ones. */
+int vitk_copy_samples(const void* src, void* dst, const int64_t* idx, int64_t n, int64_t sample_bytes, void* stream);
+
 /* Diagnostics (no counterpart in the reference): `blocks` idle workgroups that hold their CUs for about `cycles` shader
  * clocks, to measure what a launch loses when another stream's kernel occupies part of the chip. */
 int vitk_debug_hold_cus(int blocks, long long cycles, void* stream);

@@ -307,6 +307,23 @@ def test_attention_dropout_mask_is_the_same_in_both_kernel_families():
     close(o1, o2, 1e-2)
 
 
+def test_copy_samples_moves_only_the_listed_samples():
+    """vitk_copy_samples: the drop-path pass-through (samples outside the subset keep their rows, vit/transformer.py:41-46)."""
+    B, S, D = 9, 5, 24
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.float32, torch.bfloat16):
+        src = torch.randn(B * S, D, generator=g).to(DEV, dtype)
+        dst = torch.full_like(src, -7.0)
+        idx = torch.randperm(B, generator=g).to(DEV)[6:]          # a slice with a storage offset, like the caller's
+        K.copy_samples_(dst, src, idx, S * D)
+        want = torch.full_like(src, -7.0).view(B, S * D)
+        want[idx] = src.view(B, S * D)[idx]
+        assert torch.equal(dst.view(B, S * D), want)
+    K.copy_samples_(dst, src, idx[:0], S * D)   # an empty list is a no-op
+    with pytest.raises(RuntimeError, match="16-byte"):
+        K.copy_samples_(dst.view(-1, 6), src.view(-1, 6), idx, 6)
+
+
 # ---------------------------------------------------------------------------------------------- elementwise
 @pytest.mark.parametrize("dtype,emu", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
 def test_rope_matches_half_split_rotation_and_inverse_is_transpose(dtype, emu):

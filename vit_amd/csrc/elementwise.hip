@@ -877,6 +877,31 @@ extern "C" int vitk_prefix_fill(const void* cls, int64_t ncls, const void* reg, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// drop-path pass-through (vit/transformer.py:41-46: index_add leaves the samples outside the subset as they were):
+// dst[idx[i], :] = src[idx[i], :] for the listed samples, 16 bytes per thread.  The kept samples' rows are written
+// by the kernel that follows (residual epilogue / norm backward), so the merged stream is never cloned whole.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_samples_k(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                      const int64_t* __restrict__ idx, int64_t n, int64_t vec_per_sample) {
+  const int64_t total = n * vec_per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t s = idx[i / vec_per_sample], off = s * vec_per_sample + i % vec_per_sample;
+    dst[off] = src[off];
+  }
+}
+
+extern "C" int vitk_copy_samples(const void* src, void* dst, const int64_t* idx, int64_t n, int64_t sample_bytes, void* stream) {
+  VITK_REQUIRE(src && dst && (idx || n == 0) && n >= 0, "copy_samples: null pointer");
+  VITK_REQUIRE(sample_bytes > 0 && sample_bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+               "copy_samples: samples must be whole 16-byte units at 16-byte aligned addresses");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(copy_samples_k, dim3(ew_grid(n * (sample_bytes / 16))), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, (uint4*)dst, idx, n, sample_bytes / 16);
+  VITK_LAUNCH_CHECK("copy_samples");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Diagnostics: `blocks` workgroups of one wave per SIMD that stay resident for about `cycles` shader clocks and do
 // nothing -- a stand-in for a collective's kernel on a side stream, to see what a launch on the main stream loses when
 // some CUs are taken (tools/bench_hog.py).  The loop is bounded by the clock AND by an iteration count.

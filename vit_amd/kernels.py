@@ -414,6 +414,17 @@ def scale_cast(g: Tensor, rows: int, N: int, out_dtype: torch.dtype, *, row_idx:
     return out
 
 
+def copy_samples_(dst: Tensor, src: Tensor, idx: Tensor, sample_elems: int) -> Tensor:
+    """dst[idx[i]] = src[idx[i]] with dst / src viewed as [-1, sample_elems] (same dtype, contiguous; idx int64)."""
+    lib = L.load()
+    L.require_gpu(dst, src, idx)
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+    assert idx.dtype == torch.int64 and dst.numel() % sample_elems == 0
+    L.check(lib.vitk_copy_samples(L.ptr(src), L.ptr(dst), L.ptr(_c(idx)), idx.numel(), sample_elems * dst.element_size(),
+                                  L.stream()))
+    return dst
+
+
 def prefix_fill_(out: Tensor, cls_tokens: Tensor, register_tokens: Tensor) -> Tensor:
     """Rows 0 .. ncls + nreg - 1 of every sample of out [B, S, D] <- cls [1, ncls, D], register tokens [1, nreg, D]."""
     lib = L.load()

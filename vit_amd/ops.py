@@ -254,10 +254,13 @@ def _passthrough(src2: Tensor, dropped: Optional[Tensor], rows_per_sample: int) 
     if dropped is None or src2.shape[0] % rows_per_sample:
         out = src2.clone()
         return out, out
+    width = rows_per_sample * src2.shape[1]
+    if not src2.is_contiguous() or (width * src2.element_size()) % 16:
+        out = src2.clone()
+        return out, out
     out = torch.empty_like(src2)
     if dropped.numel():
-        width = rows_per_sample * src2.shape[1]
-        out.view(-1, width).index_copy_(0, dropped, src2.view(-1, width).index_select(0, dropped))
+        K.copy_samples_(out, src2, dropped, width)
     return out, src2
 
 

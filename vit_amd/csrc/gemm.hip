@@ -407,6 +407,8 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
 
 // Tile counters of the persistent kernels (dynamic tile shares): 8 per-XCD draw counters in the caller's workspace,
 // zeroed on the launch stream in front of the kernel.
+// Diagnostic build (-DEXP_NODMA, with -DEXP_STAMP): the main loop issues no operand requests (the MFMAs multiply stale LDS
+// contents), which shows what the loop costs without its L2 -> LDS traffic.
 // Diagnostic build (-DEXP_STAMP): waves 0 and 4 of every block add up the shader cycles of six segments of a tile
 // (0 set-up + wait for the first half-stage, 1 main loop, 2 post-loop synchronisation, 3 request of the next tile's first
 // half-stages, 4 epilogue, 5 final wait + barrier) into a buffer of their own, which vitk_debug_stamps copies out.
@@ -500,12 +502,16 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
 
   for (int k = 0; k < nk; k++) {
     read_frags(smem + ((2 * k) & 3) * SLOT_B);       // R0
+#ifndef EXP_NODMA
     request(2 * k + 3);
+#endif
     dma_barrier(true);
     multiply();                                      // M1
     dma_barrier(false);
     read_frags(smem + ((2 * k + 1) & 3) * SLOT_B);   // R2
+#ifndef EXP_NODMA
     request(2 * k + 4);
+#endif
     dma_barrier(true);
     multiply();                                      // M3
     dma_barrier(false);

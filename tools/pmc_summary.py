@@ -71,7 +71,7 @@ def short(name: str) -> str:
     m = re.match(r"(?:void\s+)?([A-Za-z_][\w:]*(?:\(anonymous namespace\)::)?[\w:]*)", name)
     base = m.group(1) if m else name[:60]
     if base.startswith(("gemm_", "attn_", "norm_", "rope_", "colsum", "splitk", "scale_cast", "im2col", "act_", "prefix_",
-                        "hold_")):
+                        "hold_", "copy_samples")):
         t = re.match(r"(?:void\s+)?[\w:]+<(.*?)>\(", name)
         if t:
             args = re.sub(r"__hip_bfloat16|__bf16|hip_bfloat16", "bf16", t.group(1))
@@ -108,7 +108,21 @@ def main():
     ap.add_argument("out_prefix")
     ap.add_argument("--steps", type=int, required=True, help="benchmark steps the passes ran (warm-up + timed)")
     ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline")
+    ap.add_argument("--raw-dir", default=None, help="also write the passes' counter rows (kernel names shortened) as "
+                    "<raw-dir>/{mfma,fetch,write}_counter_rows.csv")
     a = ap.parse_args()
+
+    if a.raw_dir:   # the counter rows themselves, so that every derived figure can be recomputed from the repository alone
+        os.makedirs(a.raw_dir, exist_ok=True)
+        for pass_name in ("mfma", "fetch", "write"):
+            with open(find(os.path.join(a.pmc_dir, pass_name), "counter_collection.csv"), newline="") as f, \
+                    open(os.path.join(a.raw_dir, f"{pass_name}_counter_rows.csv"), "w", newline="") as o:
+                w = csv.writer(o)
+                w.writerow(["Dispatch_Id", "Kernel", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value",
+                            "Start_Timestamp", "End_Timestamp"])
+                for r in csv.DictReader(f):
+                    w.writerow([r["Dispatch_Id"], short(r["Kernel_Name"]), r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"],
+                                r["Counter_Value"], r["Start_Timestamp"], r["End_Timestamp"]])
 
     rows = collections.defaultdict(lambda: collections.defaultdict(float))
     for pass_name, counters in (("mfma", ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")),

@@ -244,6 +244,15 @@ int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_
 int vitk_prefix_fill(const void* cls, int64_t ncls, const void* reg, int64_t nreg, int prefix_dtype, void* out, int out_dtype,
                      int64_t B, int64_t S, int64_t D, void* stream);
 
+/* ---- Fourier position features (vit/pos_enc.py:137-149: `features = grid @ w_fourier`, `cat([sin, cos], -1) / sqrt(J)`) --
+ * grid [N, Kc] fp32 coordinates (Kc = 1..3), w [Kc, J] fp32; out [N, 2 J] of out_dtype = sin | cos, scaled by 1 / sqrt(J).
+ * The D x D projection that follows is a vitk_gemm call.  Backward: dw [Kc, J] fp32 from g = d out [N, 2 J] of g_dtype
+ * (the features are recomputed, nothing is kept from the forward call). */
+int vitk_fourier_features(const float* grid, const float* w, void* out, int out_dtype, int64_t N, int64_t Kc, int64_t J,
+                          void* stream);
+int vitk_fourier_features_bwd(const float* grid, const float* w, const void* g, int g_dtype, float* dw, int64_t N, int64_t Kc,
+                              int64_t J, void* stream);
+
 /* ---- drop-path pass-through (vit/transformer.py:41-46: `x.flatten(1).index_add(0, keep_indices, ...)` leaves the samples
  * outside the subset unchanged) ---------------------------------------------------------------------------------------
  * dst[idx[i]] = src[idx[i]] for i < n, a sample being `sample_bytes` contiguous bytes (a multiple of 16; src and dst 16-byte

@@ -307,6 +307,30 @@ def test_attention_dropout_mask_is_the_same_in_both_kernel_families():
     close(o1, o2, 1e-2)
 
 
+@pytest.mark.parametrize("dims", [(16, 16), (5, 7), (3, 4, 5)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_fourier_features_forward_backward(dims, out_dtype):
+    """vitk_fourier_features / _bwd against the reference's op sequence (vit/pos_enc.py:137-149) in torch."""
+    import math
+
+    from vit_amd import ops
+    from vit_amd.pos_enc import create_grid
+    J = 24
+    g = torch.Generator().manual_seed(len(dims) * 100 + dims[0])
+    grid = create_grid(dims, device=DEV)
+    w = torch.randn(len(dims), J, generator=g).to(DEV).requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    f = grid @ wr
+    ref = torch.cat([f.sin(), f.cos()], dim=-1) / math.sqrt(J)
+    got = ops.FourierFeaturesFn.apply(grid, w, out_dtype)
+    assert got.shape == ref.shape and got.dtype == out_dtype
+    close(got, ref.to(out_dtype), 1e-5 if out_dtype == torch.float32 else 8e-3)
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    ref.backward(dy.to(out_dtype).float())
+    got.backward(dy.to(out_dtype))
+    close(w.grad, wr.grad, 1e-4)
+
+
 def test_copy_samples_moves_only_the_listed_samples():
     """vitk_copy_samples: the drop-path pass-through (samples outside the subset keep their rows, vit/transformer.py:41-46)."""
     B, S, D = 9, 5, 24

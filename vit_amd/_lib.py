@@ -19,7 +19,7 @@ EXPORTS = [
     "vitk_version", "vitk_last_error", "vitk_norm_fwd", "vitk_norm_bwd", "vitk_norm_bwd_workspace_bytes",
     "vitk_gemm", "vitk_gemm_workspace_bytes", "vitk_attn_fwd", "vitk_attn_bwd", "vitk_attn_weights", "vitk_rope_qk", "vitk_rope_rows", "vitk_debug_hold_cus", "vitk_act_fwd",
     "vitk_act_bwd", "vitk_im2col", "vitk_col2im", "vitk_colsum", "vitk_colsum_static", "vitk_colsum_workspace_bytes", "vitk_scale_cast",
-    "vitk_prefix_fill", "vitk_copy_samples",
+    "vitk_prefix_fill", "vitk_copy_samples", "vitk_fourier_features", "vitk_fourier_features_bwd",
 ]
 
 
@@ -100,6 +100,8 @@ def load() -> C.CDLL:
         "vitk_scale_cast": [vp, i32, i64, vp, vp, vp, i32, i64, i64, f32, f32, u64, vp],
         "vitk_prefix_fill": [vp, i64, vp, i64, i32, vp, i32, i64, i64, i64, vp],
         "vitk_copy_samples": [vp, vp, vp, i64, i64, vp],
+        "vitk_fourier_features": [vp, vp, vp, i32, i64, i64, i64, vp],
+        "vitk_fourier_features_bwd": [vp, vp, vp, i32, vp, i64, i64, i64, vp],
     }
     for name, args in sigs.items():
         if not hasattr(lib, name) and os.environ.get("VITK_LIB"):

@@ -877,6 +877,79 @@ extern "C" int vitk_prefix_fill(const void* cls, int64_t ncls, const void* reg, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fourier position features (vit/pos_enc.py:137-149, the part in front of the D x D projection):
+//   f[n, j] = sum_k grid[n, k] * w[k, j]  (k = 2 or 3 coordinates, fp32),  out[n, j] = sin(f) * scale,
+//   out[n, J + j] = cos(f) * scale,  scale = 1 / sqrt(J)   (the reference divides by sqrt(J); torch multiplies by the
+//   reciprocal).  One thread per (n, j); the backward pass recomputes f and reduces over n per block:
+//   dw[k, j] = sum_n grid[n, k] * scale * (cos(f) * g[n, j] - sin(f) * g[n, J + j]).
+// ------------------------------------------------------------------------------------------------
+template <class TO>
+__global__ __launch_bounds__(256) void fourier_fwd_k(const float* __restrict__ grid, const float* __restrict__ w,
+                                                     TO* __restrict__ out, int64_t N, int Kc, int64_t J, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * J; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / J, j = i - n * J;
+    float f = 0.f;
+    for (int k = 0; k < Kc; k++) f = fmaf(grid[n * Kc + k], w[k * J + j], f);
+    out[n * 2 * J + j] = from_f<TO>(sinf(f) * scale);
+    out[n * 2 * J + J + j] = from_f<TO>(cosf(f) * scale);
+  }
+}
+
+// one block per 64 columns j: thread (jj = tid & 63, part = tid >> 6) sums rows n = part, part + 4, ...; LDS adds the 4 parts
+template <class TG>
+__global__ __launch_bounds__(256) void fourier_bwd_k(const float* __restrict__ grid, const float* __restrict__ w,
+                                                     const TG* __restrict__ g, float* __restrict__ dw, int64_t N, int Kc,
+                                                     int64_t J, float scale) {
+  __shared__ float part_sum[4][3][64];
+  const int jj = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + jj;
+  float acc[3] = {0.f, 0.f, 0.f};
+  if (j < J) {
+    for (int64_t n = part; n < N; n += 4) {
+      float f = 0.f;
+      for (int k = 0; k < Kc; k++) f = fmaf(grid[n * Kc + k], w[k * J + j], f);
+      const float df = scale * (cosf(f) * to_f<TG>(g[n * 2 * J + j]) - sinf(f) * to_f<TG>(g[n * 2 * J + J + j]));
+      for (int k = 0; k < Kc; k++) acc[k] = fmaf(grid[n * Kc + k], df, acc[k]);
+    }
+  }
+  for (int k = 0; k < 3; k++) part_sum[part][k][jj] = acc[k];
+  __syncthreads();
+  if (part == 0 && j < J)
+    for (int k = 0; k < Kc; k++) dw[k * J + j] = (part_sum[0][k][jj] + part_sum[1][k][jj]) + (part_sum[2][k][jj] + part_sum[3][k][jj]);
+}
+
+extern "C" int vitk_fourier_features(const float* grid, const float* w, void* out, int out_dtype, int64_t N, int64_t Kc,
+                                     int64_t J, void* stream) {
+  VITK_REQUIRE(grid && w && out, "fourier_features: null pointer");
+  VITK_REQUIRE(N >= 0 && J > 0 && Kc >= 1 && Kc <= 3, "fourier_features: bad shape N=%lld K=%lld J=%lld", (long long)N,
+               (long long)Kc, (long long)J);
+  VITK_REQUIRE(out_dtype == VITK_F32 || out_dtype == VITK_BF16, "fourier_features: bad dtype");
+  if (N == 0) return 0;
+  const float scale = (float)(1.0 / sqrt((double)J));
+  DISPATCH_DTYPE(out_dtype, TO, {
+    hipLaunchKernelGGL((fourier_fwd_k<TO>), dim3(ew_grid(N * J)), dim3(256), 0, (hipStream_t)stream, grid, w, (TO*)out, N,
+                       (int)Kc, J, scale);
+  });
+  VITK_LAUNCH_CHECK("fourier_features");
+  return 0;
+}
+
+extern "C" int vitk_fourier_features_bwd(const float* grid, const float* w, const void* g, int g_dtype, float* dw, int64_t N,
+                                         int64_t Kc, int64_t J, void* stream) {
+  VITK_REQUIRE(grid && w && g && dw, "fourier_features_bwd: null pointer");
+  VITK_REQUIRE(N >= 0 && J > 0 && Kc >= 1 && Kc <= 3, "fourier_features_bwd: bad shape N=%lld K=%lld J=%lld", (long long)N,
+               (long long)Kc, (long long)J);
+  VITK_REQUIRE(g_dtype == VITK_F32 || g_dtype == VITK_BF16, "fourier_features_bwd: bad dtype");
+  const float scale = (float)(1.0 / sqrt((double)J));
+  DISPATCH_DTYPE(g_dtype, TG, {
+    hipLaunchKernelGGL((fourier_bwd_k<TG>), dim3((unsigned)ceil_div(J, 64)), dim3(256), 0, (hipStream_t)stream, grid, w,
+                       (const TG*)g, dw, N, (int)Kc, J, scale);
+  });
+  VITK_LAUNCH_CHECK("fourier_features_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // drop-path pass-through (vit/transformer.py:41-46: index_add leaves the samples outside the subset as they were):
 // dst[idx[i], :] = src[idx[i], :] for the listed samples, 16 bytes per thread.  The kept samples' rows are written
 // by the kernel that follows (residual epilogue / norm backward), so the merged stream is never cloned whole.

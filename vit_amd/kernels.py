@@ -414,6 +414,30 @@ def scale_cast(g: Tensor, rows: int, N: int, out_dtype: torch.dtype, *, row_idx:
     return out
 
 
+def fourier_features(grid: Tensor, w: Tensor, out_dtype: torch.dtype) -> Tensor:
+    """grid [N, Kc] fp32, w [Kc, J] fp32 -> [N, 2 J] = cat(sin(grid @ w), cos(grid @ w)) / sqrt(J) in out_dtype."""
+    lib = L.load()
+    L.require_gpu(grid, w)
+    assert grid.dtype == torch.float32 and w.dtype == torch.float32 and grid.shape[1] == w.shape[0]
+    grid, w = _c(grid), _c(w)
+    N, Kc, J = grid.shape[0], grid.shape[1], w.shape[1]
+    out = torch.empty((N, 2 * J), dtype=out_dtype, device=grid.device)
+    L.check(lib.vitk_fourier_features(L.ptr(grid), L.ptr(w), L.ptr(out), L.dt(out), N, Kc, J, L.stream()))
+    return out
+
+
+def fourier_features_bwd(grid: Tensor, w: Tensor, g: Tensor) -> Tensor:
+    """d w [Kc, J] fp32 from g = d features [N, 2 J]."""
+    lib = L.load()
+    L.require_gpu(grid, w, g)
+    grid, w, g = _c(grid), _c(w), _c(g)
+    N, Kc, J = grid.shape[0], grid.shape[1], w.shape[1]
+    assert g.shape == (N, 2 * J)
+    dw = torch.empty((Kc, J), dtype=torch.float32, device=grid.device)
+    L.check(lib.vitk_fourier_features_bwd(L.ptr(grid), L.ptr(w), L.ptr(g), L.dt(g), L.ptr(dw), N, Kc, J, L.stream()))
+    return dw
+
+
 def copy_samples_(dst: Tensor, src: Tensor, idx: Tensor, sample_elems: int) -> Tensor:
     """dst[idx[i]] = src[idx[i]] with dst / src viewed as [-1, sample_elems] (same dtype, contiguous; idx int64)."""
     lib = L.load()

@@ -208,6 +208,28 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     return LinearFn.apply(x, w, b, compute_dtype(w.dtype))
 
 
+class FourierFeaturesFn(torch.autograd.Function):
+    """cat([sin(grid @ w), cos(grid @ w)], -1) / sqrt(J) in one launch, in the dtype the projection behind it computes in
+    (vit/pos_enc.py:137-149; the reference forms the features in fp32 with autocast off and the linear casts them)."""
+
+    @staticmethod
+    def forward(ctx, grid, w, out_dtype):
+        L.require_gpu(grid, w)
+        g2 = grid.detach().reshape(-1, grid.shape[-1]).float()
+        w2 = w.detach().float()
+        ctx.save_for_backward(g2, w2)
+        ctx.wdtype = w.dtype
+        return K.fourier_features(g2, w2, out_dtype).view(*grid.shape[:-1], 2 * w.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        g2, w2 = ctx.saved_tensors
+        d2 = dy.reshape(-1, dy.shape[-1])
+        if d2.dtype not in (torch.float32, torch.bfloat16):
+            d2 = d2.float()
+        return None, K.fourier_features_bwd(g2, w2, d2).to(ctx.wdtype), None
+
+
 # ------------------------------------------------------------------------------------------------
 # F.dropout on a [..., N] tensor (N % 4 == 0): mask from (seed, element index), regenerated in backward
 # ------------------------------------------------------------------------------------------------

@@ -35,9 +35,14 @@ def create_grid(dims: Sequence[int], dtype=torch.float32, device="cpu", normaliz
 
 
 def fourier_position(dims: Sequence[int], w_fourier: Tensor, w_fc1: Tensor, b_fc1: Optional[Tensor]) -> Tensor:
-    with torch.autocast(device_type=w_fourier.device.type, enabled=False):
-        feats = create_grid(dims, device=w_fourier.device) @ w_fourier
-        feats = torch.cat([feats.sin(), feats.cos()], dim=-1) / math.sqrt(w_fourier.shape[-1])
+    grid = create_grid(dims, device=w_fourier.device)
+    if len(dims) <= 3 and w_fourier.dtype == torch.float32:   # other dtypes fail below exactly as they do in the reference
+        # features in fp32 arithmetic, rounded once to the dtype the projection computes in (what its input cast does)
+        feats = ops.FourierFeaturesFn.apply(grid, w_fourier, ops.compute_dtype(w_fc1.dtype))
+    else:
+        with torch.autocast(device_type=w_fourier.device.type, enabled=False):
+            feats = grid @ w_fourier
+            feats = torch.cat([feats.sin(), feats.cos()], dim=-1) / math.sqrt(w_fourier.shape[-1])
     return ops.linear(feats, w_fc1, b_fc1)
 
 

@@ -62,7 +62,9 @@ def token_rows(keep_idx: Optional[Tensor], S: int) -> Optional[Tensor]:
     key = (S, keep_idx.device)
     ar = _ARANGE.get(key)
     if ar is None:
-        ar = _ARANGE[key] = torch.arange(S, device=keep_idx.device, dtype=torch.int64)[None, :]
+        ar = torch.arange(S, device=keep_idx.device, dtype=torch.int64)[None, :]
+        if len(_ARANGE) < 64:   # a handful of sequence lengths per process; never an unbounded cache
+            _ARANGE[key] = ar
     return torch.add(ar, keep_idx.to(torch.int64)[:, None], alpha=S).reshape(-1)   # one launch: keep_idx * S + arange(S)
 
 

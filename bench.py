@@ -150,6 +150,29 @@ def cpu_baseline(w: dict, seconds: float = 20.0) -> dict:
                       f"({os.cpu_count()} logical CPUs visible)"}
 
 
+def cpu_baseline_config1() -> dict:
+    """BASELINE config 1 exactly, on the host cores: ViT-S/16 224 px fp32 forward, batch 8, eval + inference_mode,
+    3 warm-up + 20 timed iterations of the oracle (the reference's benchmark/benchmark.py:51-84 loop)."""
+    from oracle import vit_oracle as O
+
+    w = WORKLOADS["vit_s16_224_fp32_fwd"]
+    kw = dict(w["cfg"])
+    kw["dtype"] = getattr(torch, kw["dtype"])
+    cfg = O.OracleConfig(**kw)
+    sd = O.init_state(cfg, seed=0)
+    x = torch.randn(8, cfg.in_channels, *cfg.img_size)
+    with torch.inference_mode():
+        for _ in range(3):
+            O.vit_forward(cfg, sd, x, training=False)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            O.vit_forward(cfg, sd, x, training=False)
+        el = time.perf_counter() - t0
+    return {"workload": "vit_s16_224_fp32_fwd", "value": round(20 * 8 / el, 2), "unit": "images/s", "ms_per_batch": round(el / 20 * 1e3, 2),
+            "cores": torch.get_num_threads(), "cpu_count": os.cpu_count(), "kind": "port",
+            "sample": "20 forward passes of batch 8 after 3 warm-up passes, eval + inference_mode, fp32"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,6 +294,8 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w)
+            if args.workload.startswith("vit_b14"):   # the headline run also times the reference's own CPU case
+                rec["cpu_baseline_config1"] = cpu_baseline_config1()
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -316,7 +316,10 @@ __device__ __forceinline__ uint32_t clip32(int64_t v) { return v > 0xfffffff0ll 
 // slab (the epilogues are paced by the issue of their stores).  Used by STORE with bf16 output, GLU and DGLU; their
 // arithmetic (and rounding points) is that of the 4-column forms above.
 template <int MODE, class TO>
-constexpr bool epi_wide() { return MODE == EPI_GLU || MODE == EPI_DGLU || MODE == EPI_ROPE || (MODE == VITK_EPI_STORE && sizeof(TO) == 2); }
+constexpr bool epi_wide() {
+  return MODE == EPI_GLU || MODE == EPI_DGLU || MODE == EPI_ACT || MODE == EPI_DACT || MODE == EPI_ROPE ||
+         (MODE == VITK_EPI_STORE && sizeof(TO) == 2);
+}
 
 struct Raw8 {   // 8 bf16 as loaded
   uint4 q;
@@ -414,6 +417,41 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, fl
   store8((TI*)e.out + m * e.ldo + F + n, dg);
 }
 
+// ACT, 8 columns: v = fc1 output (bias added) of row m, columns n..n+7 (see EpiVec, EPI_ACT)
+__device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, float (&v)[8]) {
+  typedef bf16 TI;
+  store8((TI*)e.aux + m * e.N + n, v);
+  float o[8];
+  ACT_SWITCH(e.act, ACT, {
+    _Pragma("unroll")
+    for (int j = 0; j < 8; j++) o[j] = act_apply_t<ACT>(round_as<TI>(v[j]));
+  });
+  if (e.thr) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
+  }
+  store8((TI*)e.out + m * e.ldo + n, o);
+}
+
+// DACT, 8 columns: v = dh[m, n..n+7]; pa = saved pre-activations (see EpiVec, EPI_DACT)
+__device__ __forceinline__ void epi_dact8(const Epi& e, int64_t m, int64_t n, float (&v)[8], const Raw8& pa) {
+  typedef bf16 TI;
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = round_as<TI>(v[j]);
+  if (e.thr) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+  }
+  float o[8];
+  ACT_SWITCH(e.act, ACT, {
+    _Pragma("unroll")
+    for (int j = 0; j < 8; j++) o[j] = v[j] * act_grad_t<ACT>(pa.get(j));
+  });
+  store8((TI*)e.out + m * e.ldo + n, o);
+}
+
 template <int MODE, class TO>
 struct EpiCols {  // per-lane column constants, loaded once per tile
   float bias0[4], bias1[4], gam[4];
@@ -497,11 +535,15 @@ __device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, 
                                               int64_t mbase, int64_t M, int64_t N, int lane) {
   if (!epi_reads_memory<MODE>()) return;
   constexpr int EMODE = MODE < 0 ? 0 : MODE;
-  if (epi_wide<MODE, TO>()) {   // DGLU: the slab's first row per lane; slab_finish requests the others one ahead of their use
+  if (epi_wide<MODE, TO>()) {   // DGLU / DACT: the slab's first row per lane; slab_finish requests the others one ahead of their use
     const int64_t m = mbase + (lane >> 3);
     if (m < M && cols.ncol < N) {
-      pre.wa[0].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol);
-      pre.wb[0].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol);
+      if (MODE == EPI_DACT) {
+        pre.wa[0].load((const bf16*)e.aux + m * e.N + cols.ncol);
+      } else {
+        pre.wa[0].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol);
+        pre.wb[0].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol);
+      }
     }
     return;
   }
@@ -555,9 +597,15 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
         pre.wa[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * 2 * e.N + ncol);
         pre.wb[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * 2 * e.N + e.N + ncol);
       }
+      if (MODE == EPI_DACT && it < 3 && m + 8 < M && ncol < N) pre.wa[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * e.N + ncol);
       if (m < M && ncol < N) {
         if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, v, pre.wa[it & 1], pre.wb[it & 1]);
-        else {
+        else if (MODE == EPI_DACT) epi_dact8(e, m, ncol, v, pre.wa[it & 1]);
+        else if (MODE == EPI_ACT) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
+          epi_act8(e, m, ncol, v);
+        } else {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
           if (MODE == EPI_ROPE && ncol < 2 * e.rope_width) {

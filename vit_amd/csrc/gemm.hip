@@ -632,10 +632,10 @@ static bool mfma_ok(const VitkGemm* g) {
   if (ep == VITK_EPI_ROPE && g->out_dtype != VITK_BF16) return false;
   if ((ep == VITK_EPI_DACT || ep == VITK_EPI_DGLU) && !nn) return false;
   if (ep == VITK_EPI_GLU && g->N % 64) return false;
-  // the epilogue moves 4 columns per lane with vector accesses, 8 for bf16 outputs of STORE / ACT / GLU / DACT / DGLU / ROPE
+  // the epilogue moves 4 columns per lane with vector accesses, 8 for bf16 outputs of every mode but PATCH
   if (g->N % 4 || g->ldo % 4) return false;
   if (g->out_dtype == VITK_BF16 && (ep == VITK_EPI_STORE || ep == VITK_EPI_GLU || ep == VITK_EPI_DGLU || ep == VITK_EPI_ROPE ||
-                                   ep == VITK_EPI_ACT || ep == VITK_EPI_DACT) && (g->N % 8 || g->ldo % 8))
+                                   ep == VITK_EPI_ACT || ep == VITK_EPI_DACT || ep == VITK_EPI_RESIDUAL) && (g->N % 8 || g->ldo % 8))
     return false;
   if (!aligned16(g->out) || !aligned16(g->res) || !aligned16(g->aux) || !aligned16(g->bias) || !aligned16(g->gamma) ||
       !aligned16(g->pos))

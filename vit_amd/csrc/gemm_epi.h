@@ -318,7 +318,7 @@ __device__ __forceinline__ uint32_t clip32(int64_t v) { return v > 0xfffffff0ll 
 template <int MODE, class TO>
 constexpr bool epi_wide() {
   return MODE == EPI_GLU || MODE == EPI_DGLU || MODE == EPI_ACT || MODE == EPI_DACT || MODE == EPI_ROPE ||
-         (MODE == VITK_EPI_STORE && sizeof(TO) == 2);
+         ((MODE == VITK_EPI_STORE || MODE == VITK_EPI_RESIDUAL) && sizeof(TO) == 2);
 }
 
 struct Raw8 {   // 8 bf16 as loaded
@@ -417,6 +417,30 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, fl
   store8((TI*)e.out + m * e.ldo + F + n, dg);
 }
 
+// RESIDUAL on a bf16 stream, 8 columns: v = linear output (bias added) of row m; res = the residual row `row`, columns
+// n..n+7 as loaded; gam = layer scale (ones without one).  Arithmetic and rounding points of EpiVec's RESIDUAL form.
+__device__ __forceinline__ void epi_res8(const Epi& e, int64_t m, int64_t row, int64_t n, float (&v)[8], const float (&gam)[8],
+                                         const Raw8& res) {
+  typedef bf16 T;
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = round_as<T>(v[j]);
+  if (e.thr) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<T>(v[j] * e.keep_scale) : 0.f;
+  }
+  if (e.aux) store8((T*)e.aux + m * e.N + n, v);
+  float r[8];
+  if (e.gamma) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = res.get(j) + e.alpha * round_as<T>(v[j] * gam[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = res.get(j) + e.alpha * v[j];
+  }
+  store8((T*)e.out + row * e.ldo + n, r);
+}
+
 // ACT, 8 columns: v = fc1 output (bias added) of row m, columns n..n+7 (see EpiVec, EPI_ACT)
 __device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, float (&v)[8]) {
   typedef bf16 TI;
@@ -486,6 +510,16 @@ struct EpiCols {  // per-lane column constants, loaded once per tile
             for (int j = 0; j < 8; j++) wb1[j] = b.get(j);
           }
         }
+        if (MODE == VITK_EPI_RESIDUAL) {   // layer scale of this lane's 8 columns (bf16 stream: gamma is bf16 too)
+#pragma unroll
+          for (int j = 0; j < 8; j++) wb1[j] = 1.f;
+          if (e.gamma && ncol < N) {
+            Raw8 g;
+            g.load((const bf16*)e.gamma + ncol);
+#pragma unroll
+            for (int j = 0; j < 8; j++) wb1[j] = g.get(j);
+          }
+        }
       }
     } else if (MODE == EPI_GLU) {
       const int cv = lane & 7;
@@ -525,6 +559,8 @@ template <int MODE, class TO>
 struct SlabPre {
   EpiPre<(MODE < 0 ? 0 : MODE), TO> r[8];
   Raw8 wa[2], wb[2];   // 8-column DGLU: linear and gate pre-activations of the row being finished and of the next one
+  Raw8 wr[4];          // 8-column RESIDUAL (bf16 stream): the slab's four residual rows of this lane
+  int64_t wrow[4];
 };
 
 template <int MODE>
@@ -536,6 +572,17 @@ __device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, 
   if (!epi_reads_memory<MODE>()) return;
   constexpr int EMODE = MODE < 0 ? 0 : MODE;
   if (epi_wide<MODE, TO>()) {   // DGLU / DACT: the slab's first row per lane; slab_finish requests the others one ahead of their use
+    if (MODE == VITK_EPI_RESIDUAL) {
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int64_t mr = mbase + it * 8 + (lane >> 3);
+        if (mr < M && cols.ncol < N) {
+          pre.wrow[it] = e.row_idx ? e.row_idx[mr] : mr;
+          pre.wr[it].load((const bf16*)e.res + pre.wrow[it] * e.ldo + cols.ncol);
+        }
+      }
+      return;
+    }
     const int64_t m = mbase + (lane >> 3);
     if (m < M && cols.ncol < N) {
       if (MODE == EPI_DACT) {
@@ -605,6 +652,10 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
           epi_act8(e, m, ncol, v);
+        } else if (MODE == VITK_EPI_RESIDUAL) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
+          epi_res8(e, m, pre.wrow[it], ncol, v, cols.wb1, pre.wr[it]);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];

@@ -152,7 +152,8 @@ int vitk_gemm(const VitkGemm* g, void* stream);
  * lse [B,H,S] fp32 = log-sum-exp of the scaled scores (saved for backward). delta [B,H,S] fp32 scratch.
  * Cross-attention (CrossAttention / AttentivePool, vit/attention.py:218-280, :594-667): Sk > 0 keys per sample
  * with their own strides kv_* (k, v) and dkv_* (dk, dv); S then counts the queries.  Sk = 0 is self-attention
- * (keys = queries, k/v/dk/dv use the q and dq strides).  Cross-attention runs on the portable kernels. */
+ * (keys = queries, k/v/dk/dv use the q and dq strides).  Both kernel families take either form; the fused inverse
+ * rotation (`rope`) is for self-attention only. */
 typedef struct VitkAttn {
   const void* q; const void* k; const void* v; void* o;
   const void* dout; void* dq; void* dk; void* dv;   /* backward only */

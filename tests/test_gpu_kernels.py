@@ -249,6 +249,60 @@ def test_attention_forward_backward(S, Dh, mode):
         close(dqkv[:, i * D:(i + 1) * D], dqkv_ref[:, i * D:(i + 1) * D], tol, msg="d" + name)
 
 
+def cross_attn_reference(q, kv, B, Sq, Sk, H, Dh, dout):
+    D = H * Dh
+    qd = q.double().reshape(B, Sq, H, Dh).transpose(1, 2).requires_grad_(True)
+    k, v = [t.reshape(B, Sk, H, Dh).transpose(1, 2).requires_grad_(True) for t in kv.double().reshape(B * Sk, 2, D).unbind(1)]
+    s = (qd @ k.transpose(-1, -2)) * Dh ** -0.5
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B * Sq, D)
+    o.backward(dout.double())
+    dq = qd.grad.transpose(1, 2).reshape(B * Sq, D)
+    dkv = torch.stack([t.grad.transpose(1, 2).reshape(B * Sk, D) for t in (k, v)], dim=1).reshape(B * Sk, 2 * D)
+    return o.detach(), torch.logsumexp(s, -1).detach(), dq, dkv
+
+
+@pytest.mark.parametrize("Sq,Sk,Dh", [(1, 272, 64), (3, 100, 32), (70, 197, 80), (300, 45, 88), (130, 577, 128), (64, 16, 64)])
+@pytest.mark.parametrize("mode", ["portable_fp32", "portable_bf16", "mfma"])
+def test_cross_attention_forward_backward(Sq, Sk, Dh, mode):
+    """Sq queries over Sk keys per sample (vit/attention.py:269-273 with Lq != Lk): pooling-head sized and decoder sized
+    query counts, keys shorter and longer than a 64-key tile, on the portable and on the MFMA kernels against fp64 math."""
+    B, H = 2, 3
+    D = H * Dh
+    dtype = torch.float32 if mode == "portable_fp32" else torch.bfloat16
+    algo = 2 if mode == "mfma" else 1
+    g = torch.Generator().manual_seed(Sq * 977 + Sk * 31 + Dh)
+    q = torch.randn(B * Sq, D, generator=g).to(DEV, dtype)
+    kv = torch.randn(B * Sk, 2 * D, generator=g).to(DEV, dtype)
+    dout = torch.randn(B * Sq, D, generator=g).to(DEV, dtype)
+    o, lse = K.attn_cross_fwd(q, kv, B, Sq, Sk, H, Dh, Dh ** -0.5, algo=algo)
+    dq, dkv = K.attn_cross_bwd(q, kv, o, lse, dout, B, Sq, Sk, H, Dh, Dh ** -0.5, algo=algo)
+    o_ref, lse_ref, dq_ref, dkv_ref = cross_attn_reference(q, kv, B, Sq, Sk, H, Dh, dout)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    close(o, o_ref, tol, msg="o")
+    close(lse, lse_ref, 1e-4 if dtype == torch.float32 else 1e-3, msg="lse")
+    close(dq, dq_ref, tol, msg="dq")
+    close(dkv[:, :D], dkv_ref[:, :D], tol, msg="dk")
+    close(dkv[:, D:], dkv_ref[:, D:], tol, msg="dv")
+
+
+def test_cross_attention_dropout_masks_agree_between_kernel_families():
+    """Both families draw the keep decision of (query, key) from the same counter, query * Sk + key, so with dropout on they
+    agree with each other to rounding, forward and backward."""
+    B, H, Sq, Sk, Dh, p = 2, 2, 70, 150, 64, 0.3
+    D = H * Dh
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B * Sq, D, generator=g).to(DEV, torch.bfloat16)
+    kv = torch.randn(B * Sk, 2 * D, generator=g).to(DEV, torch.bfloat16)
+    dout = torch.randn(B * Sq, D, generator=g).to(DEV, torch.bfloat16)
+    res = []
+    for algo in (1, 2):
+        o, lse = K.attn_cross_fwd(q, kv, B, Sq, Sk, H, Dh, Dh ** -0.5, drop_p=p, seed=4321, algo=algo)
+        dq, dkv = K.attn_cross_bwd(q, kv, o, lse, dout, B, Sq, Sk, H, Dh, Dh ** -0.5, drop_p=p, seed=4321, algo=algo)
+        res.append((o, dq, dkv))
+    for a, b, name in zip(res[0], res[1], ("o", "dq", "dkv")):
+        close(b, a.double(), 2e-2, msg=name)
+
+
 def test_attention_long_sequence_head_dim_88():
     """The long-sequence shape of ViT-g/14 at 1024 px: S = 5329 (84 key tiles, ragged last tile), head_dim 88 (the 96-wide
     kernel instances, 4 waves per block for S >= 2048), forward and both backward kernels against fp64 math."""

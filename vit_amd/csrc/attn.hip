@@ -23,8 +23,8 @@ struct AttnP {
   float *lse, *delta;
   int64_t B, H, S, Dh;
   int64_t q_sb, q_sh, q_ss, o_sb, o_sh, o_ss, g_sb, g_sh, g_ss;
-  // cross-attention (portable kernels only): Sk keys per sample, strides of k/v and of dk/dv.  Self-attention: Sk = S
-  // and the strides repeat those of q and dq.
+  // cross-attention: Sk keys per sample, strides of k/v and of dk/dv.  Self-attention: Sk = S and the strides repeat
+  // those of q and dq.
   int64_t Sk, k_sb, k_sh, k_ss, gk_sb, gk_sh, gk_ss;
   uint64_t seed;
   float scale, keep_scale;
@@ -519,8 +519,8 @@ struct HeadBlock {
   int xb;
   bool valid;
 };
-__device__ __forceinline__ HeadBlock head_block(const AttnP& p, int rows_per_block) {
-  const int nxb = (int)((p.S + rows_per_block - 1) / rows_per_block);
+__device__ __forceinline__ HeadBlock head_block(const AttnP& p, int64_t nrows, int rows_per_block) {
+  const int nxb = (int)((nrows + rows_per_block - 1) / rows_per_block);
   const int64_t per = 8 * (int64_t)nxb, L = blockIdx.x;
   const int64_t g = L / per, r = L - g * per;
   const int64_t hh = g * 8 + (r & 7);
@@ -614,20 +614,20 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int KS = Strides<DHP>::ROWS, VS = Strides<DHP>::COLS, TILE = 64 * KS + 64 * VS;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE];   // double buffer: one barrier per key tile
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
-  const HeadBlock hb = head_block(p, NW * 32);
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S, Sk = (int)p.Sk;
+  const HeadBlock hb = head_block(p, p.S, NW * 32);
   if (!hb.valid) return;
   const int64_t b = hb.b, h = hb.h;
   const int qrow = hb.xb * (NW * 32) + wid * 32 + (lane & 31);
   const bool wave_on = hb.xb * (NW * 32) + wid * 32 < S;   // else this wave only helps staging
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
-  const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
+  const bf16* kp = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const bf16* vp = (const bf16*)p.v + b * p.k_sb + h * p.k_sh;
 
-  const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.q_ss, S, Dh, tid);
-  const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.q_ss, S, Dh, tid);
+  const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.k_ss, Sk, Dh, tid);
+  const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.k_ss, Sk, Dh, tid);
   // two register sets: tile t+2 is requested while tile t is multiplied, so a load has two tile periods to arrive
-  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  const int ntiles = (Sk + 63) >> 6, nfull = Sk >> 6;
   // The stationary fragments are requested before the first tile: loads return in order, so the wait that precedes
   // staging tile 0 also retires them, and nothing inside the loop waits on a load the loop itself has just issued.
   bf16x8 qf[DHP / 16];
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   for (int dt = 0; dt < DHP / 32; dt++) oacc[dt] = zero;
   float m = -INFINITY;
   const float c = p.scale * LOG2E;
-  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.S;
+  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.Sk;
   stage_store<DHP, NT, NCH, KS, false>(rkA, smem, tid);
   stage_store<DHP, NT, NCH, VS, false>(rvA, smem + 64 * KS, tid);
   __syncthreads();
@@ -651,14 +651,14 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   const uint64_t st1 = __builtin_amdgcn_s_memtime();
 #endif
 
-  // full 64-key tiles, then the tail tile (staged by the last step, or above when S < 64).
+  // full 64-key tiles, then the tail tile (staged by the last step, or above when there are fewer than 64 keys).
   // step(t): nk/nv hold tile t+1, fk/fv are free for tile t+2.
   auto step = [&](int t, uint4 (&nk)[NCH], uint4 (&nv)[NCH], uint4 (&fk)[NCH], uint4 (&fv)[NCH]) {
     const char* sK = smem + (t & 1) * TILE;
     const char* sV = sK + 64 * KS;
     stage_load(fk, ksrc, t + 2);   // unconditional: a conditional load would make every later wait a full drain
     stage_load(fv, vsrc, t + 2);
-    if (wave_on) fwd_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, t * 64, S, rbase, lane);
+    if (wave_on) fwd_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, t * 64, Sk, rbase, lane);
     char* nK = smem + ((t + 1) & 1) * TILE;
     stage_store<DHP, NT, NCH, KS, false>(nk, nK, tid);
     stage_store<DHP, NT, NCH, VS, false>(nv, nK + 64 * KS, tid);
@@ -674,8 +674,8 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   if (nfull < ntiles && wave_on) {
     const char* sK = smem + (nfull & 1) * TILE;
     const char* sV = sK + 64 * KS;
-    if (S - nfull * 64 > 32) fwd_tile<DHP, 2, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, S, rbase, lane);
-    else fwd_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, S, rbase, lane);
+    if (Sk - nfull * 64 > 32) fwd_tile<DHP, 2, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, Sk, rbase, lane);
+    else fwd_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, oacc, lacc, m, c, nfull * 64, Sk, rbase, lane);
   }
 #ifdef EXP_STAMP
   const uint64_t st3 = __builtin_amdgcn_s_memtime();
@@ -739,21 +739,21 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   constexpr int KS = Strides<DHP>::COLS, VS = Strides<DHP>::ROWS;  // K is read both ways (swizzled), V row-wise only
   constexpr int TILE = 64 * KS + 64 * VS;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
-  const HeadBlock hb = head_block(p, NW * 32);
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S, Sk = (int)p.Sk;
+  const HeadBlock hb = head_block(p, p.S, NW * 32);
   if (!hb.valid) return;
   const int64_t b = hb.b, h = hb.h;
   const int qrow = hb.xb * (NW * 32) + wid * 32 + (lane & 31);
   const bool qv = qrow < S;
   const bool wave_on = hb.xb * (NW * 32) + wid * 32 < S;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
-  const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
+  const bf16* kp = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const bf16* vp = (const bf16*)p.v + b * p.k_sb + h * p.k_sh;
   const bf16* gp = (const bf16*)p.dout + b * p.o_sb + h * p.o_sh;
 
-  const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.q_ss, S, Dh, tid);
-  const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.q_ss, S, Dh, tid);
-  const int ntiles = (S + 63) >> 6, nfull = S >> 6;
+  const TileSrc<NCH> ksrc = make_tilesrc<DHP, NT, NCH>(kp, p.k_ss, Sk, Dh, tid);
+  const TileSrc<NCH> vsrc = make_tilesrc<DHP, NT, NCH>(vp, p.k_ss, Sk, Dh, tid);
+  const int ntiles = (Sk + 63) >> 6, nfull = Sk >> 6;
   // stationary operands first (see attn_fwd_k)
   bf16x8 qf[DHP / 16], gf[DHP / 16], of[DHP / 16];
   load_stationary<DHP>(qf, qp, p.q_ss, qrow, S, Dh, lane);
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
     if (qv && lane < 32) p.delta[srow] = delta;
   }
   const float c = p.scale * LOG2E;
-  const uint64_t rbase = (uint64_t)srow * p.S;
+  const uint64_t rbase = (uint64_t)srow * p.Sk;
   const f32x16 zero = ZERO16;
   f32x16 dqacc[DHP / 32];
 #pragma unroll
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
     const char* sV = sK + 64 * KS;
     stage_load(fk, ksrc, t + 2);   // unconditional: a conditional load would make every later wait a full drain
     stage_load(fv, vsrc, t + 2);
-    if (wave_on) dq_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, t * 64, S, rbase, lane);
+    if (wave_on) dq_tile<DHP, 2, false, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, t * 64, Sk, rbase, lane);
     char* nK = smem + ((t + 1) & 1) * TILE;
     stage_store<DHP, NT, NCH, KS, true>(nk, nK, tid);
     stage_store<DHP, NT, NCH, VS, false>(nv, nK + 64 * KS, tid);
@@ -805,8 +805,8 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   if (nfull < ntiles && wave_on) {
     const char* sK = smem + (nfull & 1) * TILE;
     const char* sV = sK + 64 * KS;
-    if (S - nfull * 64 > 32) dq_tile<DHP, 2, true, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, nfull * 64, S, rbase, lane);
-    else dq_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, nfull * 64, S, rbase, lane);
+    if (Sk - nfull * 64 > 32) dq_tile<DHP, 2, true, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, nfull * 64, Sk, rbase, lane);
+    else dq_tile<DHP, 1, true, DROP, KS, VS>(p, sK, sV, qf, gf, dqacc, nlse2, delta, c, nfull * 64, Sk, rbase, lane);
   }
   if (!qv) return;
   bf16* dst = (bf16*)p.dq + b * p.g_sb + h * p.g_sh + (int64_t)qrow * p.g_ss;
@@ -849,7 +849,7 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
         const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
         float pd = pr, dp = pacc[r];
         if (DROP) {
-          const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.S + (uint64_t)krow) >= p.thr;
+          const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.Sk + (uint64_t)krow) >= p.thr;
           pd = keep ? pr * p.keep_scale : 0.f;
           dp = keep ? dp * p.keep_scale : 0.f;
         }
@@ -882,15 +882,15 @@ __global__ __launch_bounds__(NW * 64, (((DHP <= 64 || (DHP <= 96 && NW == 4)) &&
   constexpr int QS = Strides<DHP>::COLS;   // Q and dO tiles are read both ways (swizzled)
   constexpr int TILE = 2 * 64 * QS + 512;  // Q, dO, then -lse*log2e [64] and delta [64]
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S;
-  const HeadBlock hb = head_block(p, NW * 32);
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), Dh = (int)p.Dh, S = (int)p.S, Sk = (int)p.Sk;
+  const HeadBlock hb = head_block(p, p.Sk, NW * 32);
   if (!hb.valid) return;
   const int64_t b = hb.b, h = hb.h;
   const int krow = hb.xb * (NW * 32) + wid * 32 + (lane & 31);
-  const bool wave_on = hb.xb * (NW * 32) + wid * 32 < S;
+  const bool wave_on = hb.xb * (NW * 32) + wid * 32 < Sk;
   const bf16* qp = (const bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const bf16* kp = (const bf16*)p.k + b * p.q_sb + h * p.q_sh;
-  const bf16* vp = (const bf16*)p.v + b * p.q_sb + h * p.q_sh;
+  const bf16* kp = (const bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const bf16* vp = (const bf16*)p.v + b * p.k_sb + h * p.k_sh;
   const bf16* gp = (const bf16*)p.dout + b * p.o_sb + h * p.o_sh;
   const int64_t sbase = (b * p.H + h) * p.S;
 
@@ -910,8 +910,8 @@ __global__ __launch_bounds__(NW * 64, (((DHP <= 64 || (DHP <= 96 && NW == 4)) &&
     rl = wid == 0 ? (qq < S ? -v * LOG2E : -INFINITY) : v;
   };
   bf16x8 kf[DHP / 16], vf[DHP / 16];   // stationary operands first (see attn_fwd_k)
-  load_stationary<DHP>(kf, kp, p.q_ss, krow, S, Dh, lane);
-  load_stationary<DHP>(vf, vp, p.q_ss, krow, S, Dh, lane);
+  load_stationary<DHP>(kf, kp, p.k_ss, krow, Sk, Dh, lane);
+  load_stationary<DHP>(vf, vp, p.k_ss, krow, Sk, Dh, lane);
   stage_load(rqA, qsrc, 0);
   stage_load(rgA, gsrc, 0);
   load_row_consts(rlA, 0);
@@ -972,12 +972,12 @@ __global__ __launch_bounds__(NW * 64, (((DHP <= 64 || (DHP <= 96 && NW == 4)) &&
     if (S - nfull * 64 > 32) dkdv_tile<DHP, 2, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, nfull * 64, sbase, krow, lane);
     else dkdv_tile<DHP, 1, DROP, QS>(p, sQ, sG, sL, kf, vf, dkacc, dvacc, c, nfull * 64, sbase, krow, lane);
   }
-  if (krow >= S) return;
-  store_rows<DHP>((bf16*)p.dv + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss, dvacc, 1.f, Dh, lane);
-  bf16* dst = (bf16*)p.dk + b * p.g_sb + h * p.g_sh + (int64_t)krow * p.g_ss;
+  if (krow >= Sk) return;
+  store_rows<DHP>((bf16*)p.dv + b * p.gk_sb + h * p.gk_sh + (int64_t)krow * p.gk_ss, dvacc, 1.f, Dh, lane);
+  bf16* dst = (bf16*)p.dk + b * p.gk_sb + h * p.gk_sh + (int64_t)krow * p.gk_ss;
   if constexpr (DHP == 64) {
     if (p.rope) {
-      store_rows_rope64(dst, dkacc, p.scale, lane, p.rope, krow - p.rope_prefix, S - p.rope_prefix, p.rope_emu);
+      store_rows_rope64(dst, dkacc, p.scale, lane, p.rope, krow - p.rope_prefix, Sk - p.rope_prefix, p.rope_emu);
       return;
     }
   }
@@ -1007,7 +1007,6 @@ static AttnP make_p(const VitkAttn* a) {
 }
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool attn_mfma_ok(const VitkAttn* a, bool bwd) {
-  if (a->Sk > 0) return false;   // cross-attention (its own key count and k/v strides) runs on the portable kernels
   if (a->dtype != VITK_BF16 || a->Dh % 8 || a->Dh > 128 || a->Dh < 8) return false;
   const int64_t st[] = {a->q_sb, a->q_sh, a->q_ss, a->o_sb, a->o_sh, a->o_ss};
   for (int64_t s : st) if (s % 8) return false;
@@ -1015,6 +1014,10 @@ static bool attn_mfma_ok(const VitkAttn* a, bool bwd) {
   if (!al16(a->o)) return false;
   // operand rows are addressed with 32-bit byte offsets inside one (batch, head) slice
   if (a->S * a->q_ss * 2 >= (1ll << 30) || a->S * a->o_ss * 2 >= (1ll << 30)) return false;
+  if (a->Sk > 0) {   // cross-attention: keys and values with a row count and strides of their own
+    if (a->kv_sb % 8 || a->kv_sh % 8 || a->kv_ss % 8 || a->Sk * a->kv_ss * 2 >= (1ll << 30)) return false;
+    if (bwd && (a->dkv_sb % 8 || a->dkv_sh % 8 || a->dkv_ss % 8)) return false;
+  }
   if (bwd) {
     if (a->dq_sb % 8 || a->dq_sh % 8 || a->dq_ss % 8) return false;
     if (!al16(a->dout) || !al16(a->dq) || !al16(a->dk) || !al16(a->dv)) return false;
@@ -1099,13 +1102,14 @@ extern "C" int vitk_attn_bwd(const VitkAttn* a, void* stream) {
   const bool can = attn_mfma_ok(a, true);
   VITK_REQUIRE(a->algo != 2 || can, "attn_bwd: MFMA kernel cannot take this problem (dtype/alignment/head_dim)");
   if (a->rope)
-    VITK_REQUIRE(can && a->algo != 1 && a->Dh == 64 && a->rope_prefix >= 0 && a->rope_prefix < a->S && ((uintptr_t)a->rope & 15) == 0,
-                 "attn_bwd: the fused inverse rotation needs the MFMA kernels, head_dim 64 and 0 <= rope_prefix < S");
+    VITK_REQUIRE(can && a->algo != 1 && a->Dh == 64 && a->Sk == 0 && a->rope_prefix >= 0 && a->rope_prefix < a->S &&
+                     ((uintptr_t)a->rope & 15) == 0,
+                 "attn_bwd: the fused inverse rotation needs the MFMA kernels, self-attention, head_dim 64 and 0 <= rope_prefix < S");
   if (can && a->algo != 1) {
-    const int nw = pick_nw(a->S, a->Dh, false);
-    dim3 grid(head_block_grid(a->B, a->H, a->S, nw * 32));
-    ATTN_DISPATCH_DH(attn_dq_k, a->Dh, nw, grid, p, st);    // also writes delta
-    ATTN_DISPATCH_DH(attn_dkdv_k, a->Dh, nw, grid, p, st);  // reads delta
+    const int nw = pick_nw(a->S, a->Dh, false), nwk = pick_nw(p.Sk, a->Dh, false);
+    dim3 grid(head_block_grid(a->B, a->H, a->S, nw * 32)), gridk(head_block_grid(a->B, a->H, p.Sk, nwk * 32));
+    ATTN_DISPATCH_DH(attn_dq_k, a->Dh, nw, grid, p, st);       // also writes delta
+    ATTN_DISPATCH_DH(attn_dkdv_k, a->Dh, nwk, gridk, p, st);   // reads delta
   } else {
     if (a->dtype == VITK_F32) hipLaunchKernelGGL((attn_delta_k<float>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_delta_k<bf16>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, p);

@@ -250,7 +250,7 @@ def attn_bwd(qkv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, S: int, 
 
 
 def _cross_desc(q: Tensor, kv: Tensor, o: Tensor, lse: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: int, scale: float,
-                drop_p: float, seed: int) -> L.VitkAttn:
+                drop_p: float, seed: int, algo: Optional[int] = None) -> L.VitkAttn:
     """q [B*Sq, H*Dh]; kv [B*Sk, 2*H*Dh] = [k | v]; o [B*Sq, H*Dh]."""
     D = H * Dh
     a = L.VitkAttn()
@@ -262,12 +262,12 @@ def _cross_desc(q: Tensor, kv: Tensor, o: Tensor, lse: Tensor, B: int, Sq: int, 
     a.o_sb, a.o_sh, a.o_ss = Sq * D, Dh, D
     a.seed, a.scale, a.drop_p = seed & 0xFFFFFFFFFFFFFFFF, scale, drop_p
     a.dtype = L.dt(q)
-    a.algo = 0
+    a.algo = _ALGO if algo is None else algo
     return a
 
 
 def attn_cross_fwd(q: Tensor, kv: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: int, scale: float, drop_p: float = 0.0,
-                   seed: int = 0):
+                   seed: int = 0, algo: Optional[int] = None):
     """Attention of Sq queries over Sk keys per sample (vit/attention.py:269-273 with Lq != Lk)."""
     lib = L.load()
     L.require_gpu(q, kv)
@@ -276,13 +276,13 @@ def attn_cross_fwd(q: Tensor, kv: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: 
     assert q.dtype == kv.dtype
     o = torch.empty_like(q)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-    a = _cross_desc(q, kv, o, lse, B, Sq, Sk, H, Dh, scale, drop_p, seed)
+    a = _cross_desc(q, kv, o, lse, B, Sq, Sk, H, Dh, scale, drop_p, seed, algo)
     L.check(lib.vitk_attn_fwd(C.byref(a), L.stream()))
     return o, lse
 
 
 def attn_cross_bwd(q: Tensor, kv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, B: int, Sq: int, Sk: int, H: int, Dh: int,
-                   scale: float, drop_p: float = 0.0, seed: int = 0):
+                   scale: float, drop_p: float = 0.0, seed: int = 0, algo: Optional[int] = None):
     """Returns (dq [B*Sq, D], dkv [B*Sk, 2D])."""
     lib = L.load()
     L.require_gpu(q, kv, o, lse, dout)
@@ -290,7 +290,7 @@ def attn_cross_bwd(q: Tensor, kv: Tensor, o: Tensor, lse: Tensor, dout: Tensor, 
     D = H * Dh
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-    a = _cross_desc(q, kv, o, lse, B, Sq, Sk, H, Dh, scale, drop_p, seed)
+    a = _cross_desc(q, kv, o, lse, B, Sq, Sk, H, Dh, scale, drop_p, seed, algo)
     a.dout, a.delta = L.ptr(dout), L.ptr(delta)
     a.dq, a.dk, a.dv = dq.data_ptr(), dkv.data_ptr(), dkv.data_ptr() + D * dkv.element_size()
     a.dq_sb, a.dq_sh, a.dq_ss = Sq * D, Dh, D

@@ -186,7 +186,7 @@ def test_gemm_patch_epilogue_places_rows():
 # ---------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("ln", [False, True])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
-@pytest.mark.parametrize("D", [64, 768, 1408])
+@pytest.mark.parametrize("D", [64, 520, 768, 1408, 2048])
 def test_norm_forward_backward(ln, xdt, ydt, D):
     R = 37
     g = torch.Generator().manual_seed(D + ln)

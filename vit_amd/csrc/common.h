@@ -77,6 +77,24 @@ template <> struct Vec4<bf16> {
   }
 };
 
+// V-wide access, V = 4 or 8 (8 for bf16 only: one 16-byte access per lane, the width at which a CU streams fastest)
+template <class T, int V> struct VecN;
+template <class T> struct VecN<T, 4> : Vec4<T> {};
+template <> struct VecN<bf16, 8> {
+  float v[8];
+  __device__ __forceinline__ void load(const bf16* p) {
+    const bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (float)t[i];
+  }
+  __device__ __forceinline__ void store(bf16* p) const {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = (bf16)v[i];
+    *(bf16x8*)p = t;
+  }
+};
+
 // ---- wave reductions (wave = 64 lanes) ---------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -3,6 +3,7 @@
 // All of them stream rows with 4-wide vector accesses (16 B fp32 / 8 B bf16 per lane), fp32 math.
 #include "common.h"
 #include <mutex>
+#include <type_traits>
 #include <string>
 
 // ------------------------------------------------------------------------------------------------
@@ -28,7 +29,7 @@ extern "C" int vitk_version(void) { return 100; }
 // ------------------------------------------------------------------------------------------------
 // normalisation forward: one wave per row, rows grid-strided
 // ------------------------------------------------------------------------------------------------
-template <class TX, class TY, class TW, bool LN>
+template <class TX, class TY, class TW, bool LN, int V = 4>
 __global__ __launch_bounds__(256) void norm_fwd_k(const TX* __restrict__ x, const TW* __restrict__ w,
                                                   const TW* __restrict__ b, TY* __restrict__ y,
                                                   float* __restrict__ rstd_out, float* __restrict__ mean_out,
@@ -43,16 +44,18 @@ __global__ __launch_bounds__(256) void norm_fwd_k(const TX* __restrict__ x, cons
     float mean = 0.f;
     if (LN) {
       float s = 0.f;
-      for (int d = lane * 4; d < D; d += 256) {
-        Vec4<TX> v; v.load(xr + d);
-        s += (v.v[0] + v.v[1]) + (v.v[2] + v.v[3]);
+      for (int d = lane * V; d < D; d += 64 * V) {
+        VecN<TX, V> v; v.load(xr + d);
+#pragma unroll
+        for (int i = 0; i < V; i += 4) s += (v.v[i] + v.v[i + 1]) + (v.v[i + 2] + v.v[i + 3]);
       }
       mean = wave_sum(s) * invD;
     }
     float s2 = 0.f;
-    for (int d = lane * 4; d < D; d += 256) {
-      Vec4<TX> v; v.load(xr + d);
-      s2 = sumsq4(s2, v.v[0] - mean, v.v[1] - mean, v.v[2] - mean, v.v[3] - mean);
+    for (int d = lane * V; d < D; d += 64 * V) {
+      VecN<TX, V> v; v.load(xr + d);
+#pragma unroll
+      for (int i = 0; i < V; i += 4) s2 = sumsq4(s2, v.v[i] - mean, v.v[i + 1] - mean, v.v[i + 2] - mean, v.v[i + 3] - mean);
     }
     const float var = wave_sum(s2) * invD;
     const float rstd = rsqrtf(var + eps);
@@ -61,17 +64,17 @@ __global__ __launch_bounds__(256) void norm_fwd_k(const TX* __restrict__ x, cons
       if (LN) mean_out[r] = mean;
     }
     TY* yr = y + r * D;
-    for (int d = lane * 4; d < D; d += 256) {
-      Vec4<TX> v; v.load(xr + d);
-      Vec4<TW> wv; wv.load(w + d);
-      Vec4<TY> o;
+    for (int d = lane * V; d < D; d += 64 * V) {
+      VecN<TX, V> v; v.load(xr + d);
+      VecN<TW, V> wv; wv.load(w + d);
+      VecN<TY, V> o;
       if (LN && b) {
-        Vec4<TW> bv; bv.load(b + d);
+        VecN<TW, V> bv; bv.load(b + d);
 #pragma unroll
-        for (int i = 0; i < 4; i++) o.v[i] = norm_apply(v.v[i] - mean, rstd, wv.v[i], bv.v[i], true);
+        for (int i = 0; i < V; i++) o.v[i] = norm_apply(v.v[i] - mean, rstd, wv.v[i], bv.v[i], true);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) o.v[i] = norm_apply(v.v[i] - mean, rstd, wv.v[i], 0.f, false);
+        for (int i = 0; i < V; i++) o.v[i] = norm_apply(v.v[i] - mean, rstd, wv.v[i], 0.f, false);
       }
       o.store(yr + d);
     }
@@ -81,10 +84,10 @@ __global__ __launch_bounds__(256) void norm_fwd_k(const TX* __restrict__ x, cons
 // ------------------------------------------------------------------------------------------------
 // normalisation backward.  Per row, with g = dy*w, xh = (x-mean)*rstd:
 //   RMS: dx = rstd*(g - xh*mean(g*xh))        LN: dx = rstd*(g - mean(g) - xh*mean(g*xh))
-// dw = sum_r dy*xh, db = sum_r dy: each wave keeps its share in registers (MAXIT*4 floats),
+// dw = sum_r dy*xh, db = sum_r dy: each wave keeps its share in registers (MAXIT*V floats),
 // the 4 waves of a block combine through LDS, one partial row per block goes to the workspace.
 // ------------------------------------------------------------------------------------------------
-template <class TG, class TX, class TW, class TO, bool LN, int MAXIT>
+template <class TG, class TX, class TW, class TO, bool LN, int MAXIT, int V = 4>
 __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, const TX* __restrict__ x,
                                                   const TW* __restrict__ w, const float* __restrict__ rstd_in,
                                                   const float* __restrict__ mean_in, const TO* add, TO* dx,
@@ -97,11 +100,11 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
   const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const float invD = 1.f / (float)D;
-  float aw[MAXIT][4], ab[MAXIT][4];
+  float aw[MAXIT][V], ab[MAXIT][V];
 #pragma unroll
   for (int it = 0; it < MAXIT; it++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) { aw[it][i] = 0.f; ab[it][i] = 0.f; }
+    for (int i = 0; i < V; i++) { aw[it][i] = 0.f; ab[it][i] = 0.f; }
 
   for (int64_t r = wave; r < rows; r += nwaves) {
     const int64_t src = row_idx ? row_idx[r] : r;
@@ -110,16 +113,16 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
     const float rstd = rstd_in[r];
     const float mean = LN ? mean_in[r] : 0.f;
     float c1 = 0.f, c2 = 0.f;
-    float xhs[MAXIT][4], gs[MAXIT][4];   // normalised row and weighted gradient, kept for the second pass
+    float xhs[MAXIT][V], gs[MAXIT][V];   // normalised row and weighted gradient, kept for the second pass
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
-      const int d = it * 256 + lane * 4;
+      const int d = it * 64 * V + lane * V;
       if (d < D) {
-        Vec4<TX> xv; xv.load(xr + d);
-        Vec4<TG> gv; gv.load(gr + d);
-        Vec4<TW> wv; wv.load(w + d);
+        VecN<TX, V> xv; xv.load(xr + d);
+        VecN<TG, V> gv; gv.load(gr + d);
+        VecN<TW, V> wv; wv.load(w + d);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < V; i++) {
           const float xh = (xv.v[i] - mean) * rstd;
           const float g = gv.v[i] * wv.v[i];
           xhs[it][i] = xh;
@@ -137,18 +140,21 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
     const TO* addr = add ? add + src * D : nullptr;
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
-      const int d = it * 256 + lane * 4;
+      const int d = it * 64 * V + lane * V;
       if (d < D) {
-        Vec4<TO> o;
+        VecN<TO, V> o;
         if (addr) o.load(addr + d);
-        else { o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.f; }
+        else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) o.v[i] += rstd * (gs[it][i] - c1 - xhs[it][i] * c2);
+          for (int i = 0; i < V; i++) o.v[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < V; i++) o.v[i] += rstd * (gs[it][i] - c1 - xhs[it][i] * c2);
         o.store(outr + d);
         if (shadow) {   // the next consumer multiplies this gradient in bf16: hand it the cast along with the fp32 rows
-          Vec4<bf16> sv;
+          VecN<bf16, V> sv;
 #pragma unroll
-          for (int i = 0; i < 4; i++) sv.v[i] = round_as<TO>(o.v[i]);
+          for (int i = 0; i < V; i++) sv.v[i] = round_as<TO>(o.v[i]);
           sv.store(shadow + src * D + d);
         }
       }
@@ -158,10 +164,10 @@ __global__ __launch_bounds__(256) void norm_bwd_k(const TG* __restrict__ dy, con
   float* mine = lds + (size_t)wid * 2 * D;
 #pragma unroll
   for (int it = 0; it < MAXIT; it++) {
-    const int d = it * 256 + lane * 4;
+    const int d = it * 64 * V + lane * V;
     if (d < D) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) { mine[d + i] = aw[it][i]; mine[D + d + i] = ab[it][i]; }
+      for (int i = 0; i < V; i++) { mine[d + i] = aw[it][i]; mine[D + d + i] = ab[it][i]; }
     }
   }
   __syncthreads();
@@ -335,6 +341,7 @@ extern "C" int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const
 // ------------------------------------------------------------------------------------------------
 // norm entry points
 // ------------------------------------------------------------------------------------------------
+static bool wide_ok(const void* p) { return ((uintptr_t)p & 15) == 0; }   // null or 16-byte aligned
 static int norm_grid(int64_t rows) {
   int64_t g = ceil_div(rows, 4);
   return (int)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
@@ -344,6 +351,19 @@ template <class TX, class TY, class TW>
 static void norm_fwd_launch(const void* x, const void* w, const void* b, void* y, float* rstd, float* mean,
                             const int64_t* idx, int64_t rows, int D, float eps, int ln, hipStream_t st) {
   dim3 grid(norm_grid(rows)), block(256);
+  if constexpr (std::is_same<TX, bf16>::value && std::is_same<TY, bf16>::value && std::is_same<TW, bf16>::value) {
+    // an all-bf16 stream: 8 elements (16 bytes) per lane.  Rows shorter than one pass of the wave keep the 4-wide order
+    // of summation, which the fused per-head normalisation reproduces bit for bit.
+    if (D % 8 == 0 && D >= 512 && wide_ok(x) && wide_ok(y) && wide_ok(w) && wide_ok(b)) {
+      if (ln)
+        hipLaunchKernelGGL((norm_fwd_k<bf16, bf16, bf16, true, 8>), grid, block, 0, st, (const bf16*)x, (const bf16*)w,
+                           (const bf16*)b, (bf16*)y, rstd, mean, idx, rows, D, eps);
+      else
+        hipLaunchKernelGGL((norm_fwd_k<bf16, bf16, bf16, false, 8>), grid, block, 0, st, (const bf16*)x, (const bf16*)w,
+                           (const bf16*)b, (bf16*)y, rstd, mean, idx, rows, D, eps);
+      return;
+    }
+  }
   if (ln)
     hipLaunchKernelGGL((norm_fwd_k<TX, TY, TW, true>), grid, block, 0, st, (const TX*)x, (const TW*)w, (const TW*)b,
                        (TY*)y, rstd, mean, idx, rows, D, eps);
@@ -385,6 +405,21 @@ static int norm_bwd_launch(const void* dy, const void* x, const void* w, const f
   hipLaunchKernelGGL((norm_bwd_k<TG, TX, TW, TO, LN, MAXIT>), dim3(grid), dim3(256), lds, st, (const TG*)dy,        \
                      (const TX*)x, (const TW*)w, rstd, mean, (const TO*)add, (TO*)dx, idx, rows, D, ws, want_dw,    \
                      (bf16*)shadow)
+  if constexpr (std::is_same<TG, bf16>::value && std::is_same<TX, bf16>::value && std::is_same<TW, bf16>::value &&
+                std::is_same<TO, bf16>::value) {
+    if (D % 8 == 0 && D >= 512 && wide_ok(dy) && wide_ok(x) && wide_ok(w) && wide_ok(add) && wide_ok(dx)) {   // see norm_fwd_launch
+#define NB_LAUNCH8(MAXIT)                                                                                              \
+  hipLaunchKernelGGL((norm_bwd_k<bf16, bf16, bf16, bf16, LN, MAXIT, 8>), dim3(grid), dim3(256), lds, st, (const bf16*)dy, \
+                     (const bf16*)x, (const bf16*)w, rstd, mean, (const bf16*)add, (bf16*)dx, idx, rows, D, ws, want_dw,  \
+                     (bf16*)shadow)
+      if (D <= 512) NB_LAUNCH8(1);
+      else if (D <= 1024) NB_LAUNCH8(2);
+      else if (D <= 2048) NB_LAUNCH8(4);
+      else return vitk_set_error("norm_bwd: D=%d > 2048 not supported", D);
+#undef NB_LAUNCH8
+      return 0;
+    }
+  }
   if (D <= 512) NB_LAUNCH(2);
   else if (D <= 1024) NB_LAUNCH(4);
   else if (D <= 2048) NB_LAUNCH(8);

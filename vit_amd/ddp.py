@@ -43,7 +43,7 @@ def grad_sink(param_ptr: int, shape, dtype: torch.dtype) -> Optional[torch.Tenso
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "arrived", "given", "work", "issued")
+    __slots__ = ("params", "offsets", "flat", "arrived", "given", "work", "issued", "host")
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
@@ -56,6 +56,7 @@ class _Bucket:
         self.given = [False] * len(params)
         self.work = None
         self.issued = False
+        self.host = None   # CPU copy of `flat` while a host-side backend reduces it
 
 
 class BucketedGradAllReduce:
@@ -106,6 +107,10 @@ class BucketedGradAllReduce:
             self._old_dynamic = K.set_dynamic_tiles(True)
         self._avg = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
         self._div = backend != "nccl"
+        # A backend that reduces in host memory (gloo: tests and debugging, never the RCCL path) gets a host copy of the
+        # bucket made here, on the calling thread and the current stream, instead of the copies c10d would queue on
+        # side streams from its own threads.
+        self._host_staged = backend == "gloo" and any(b.flat.is_cuda for b in self.buckets)
 
     def _view(self, b: _Bucket, i: int) -> torch.Tensor:
         p = b.params[i]
@@ -143,7 +148,11 @@ class BucketedGradAllReduce:
     def _launch(self, b: _Bucket) -> None:
         b.issued = True
         if self.world > 1:
-            b.work = dist.all_reduce(b.flat, op=self._avg, group=self.group, async_op=True)
+            if self._host_staged:
+                b.host = b.flat.cpu()
+                b.work = dist.all_reduce(b.host, op=self._avg, group=self.group, async_op=True)
+            else:
+                b.work = dist.all_reduce(b.flat, op=self._avg, group=self.group, async_op=True)
 
     def finish(self) -> None:
         """Call after backward: issue the remaining buckets in order, wait for every bucket, re-arm for the next step."""
@@ -164,6 +173,9 @@ class BucketedGradAllReduce:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
+                if b.host is not None:
+                    b.flat.copy_(b.host)
+                    b.host = None
                 if self._div:
                     b.flat.div_(self.world)
             b.arrived = [False] * len(b.params)

@@ -403,9 +403,10 @@ def test_copy_samples_moves_only_the_listed_samples():
 
 
 # ---------------------------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("Dh", [32, 80, 88, 12])   # 16-byte, 16-byte, 8-byte and scalar accesses in bf16
 @pytest.mark.parametrize("dtype,emu", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
-def test_rope_matches_half_split_rotation_and_inverse_is_transpose(dtype, emu):
-    B, S, H, Dh, prefix = 2, 19, 3, 32, 4
+def test_rope_matches_half_split_rotation_and_inverse_is_transpose(dtype, emu, Dh):
+    B, S, H, prefix = 2, 19, 3, 4
     g = torch.Generator().manual_seed(11)
     qkv = torch.randn(B * S, 3 * H * Dh, generator=g).to(DEV, dtype)
     ang = torch.rand(S - prefix, Dh, generator=g) * 6.28

@@ -564,3 +564,30 @@ def test_learnable_position_train_matches_oracle(autocast):
                     num_register_tokens=2, num_cls_tokens=1, dtype=torch.float32)
     compare_with_oracle_on_gpu(cfg, 4, (32, 48), autocast, 2e-2 if autocast else 1e-4, grad_rtol=2e-2 if autocast else None,
                                oracle_device="cuda")
+
+
+def test_drop_path_subset_replayed_from_a_saved_generator_state_is_the_same_draw():
+    """The subset of a block comes from torch.randperm on the device generator; a second draw from the same generator
+    state (what activation checkpointing does when it replays a block) is served from the first one and must leave the
+    generator exactly where a real draw leaves it."""
+    from vit_amd import transformer as T
+
+    x = torch.zeros(8, 4, 16, device=DEV)
+    torch.manual_seed(515)
+    want = torch.randperm(8, device=DEV)
+    after = torch.rand(4, device=DEV)
+    T._PERMS.clear()
+    torch.manual_seed(515)
+    first, scale = T._select_keep_indices(x, 0.25, True)
+    after_first = torch.rand(4, device=DEV)
+    assert len(T._PERMS) == 1
+    torch.manual_seed(515)
+    second, _ = T._select_keep_indices(x, 0.25, True)     # same (seed, offset): no new draw
+    after_second = torch.rand(4, device=DEV)
+    assert len(T._PERMS) == 1
+    assert scale == 8 / 6
+    assert torch.equal(first, want[:6]) and torch.equal(second, want[:6])
+    assert torch.equal(first._vitk_dropped, want[6:]) and torch.equal(second._vitk_dropped, want[6:])
+    assert torch.equal(after_first, after) and torch.equal(after_second, after)
+    third, _ = T._select_keep_indices(x, 0.25, True)      # the generator has moved on: a new draw
+    assert len(T._PERMS) == 2

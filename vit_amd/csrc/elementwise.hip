@@ -668,13 +668,14 @@ __global__ __launch_bounds__(256) void rope_rows_k(T* __restrict__ x, const floa
   }
 }
 
-// vector form for head_dim % 8 == 0: a thread rotates 4 consecutive pairs (d .. d+3 with d+half .. d+half+3)
-template <class T>
+// vector form: a thread rotates V consecutive pairs (d .. d+V-1 with d+half .. d+half+V-1); V = 4 for head_dim % 8 == 0,
+// V = 8 (16-byte accesses, bf16) for head_dim % 16 == 0
+template <class T, int V = 4>
 __global__ __launch_bounds__(256) void rope_rows4_k(T* __restrict__ x, const float* __restrict__ table, int64_t B,
                                                     int64_t S, int64_t H, int64_t Dh, int64_t prefix, int64_t row_stride,
                                                     int64_t nsec, int inverse, int emu, int per_sample) {
   const int64_t half = Dh / 2;
-  const int64_t nc = half / 4;          // chunks of 4 pairs per head
+  const int64_t nc = half / V;          // chunks of V pairs per head
   const int64_t N = S - prefix;
   const int64_t total = B * N * nsec * H * nc;
   const int64_t tbs = per_sample ? N * Dh : 0;
@@ -687,20 +688,24 @@ __global__ __launch_bounds__(256) void rope_rows4_k(T* __restrict__ x, const flo
     const int64_t which = t % nsec; t /= nsec;
     const int64_t n = t % N;
     const int64_t b = t / N;
-    const int64_t d = c * 4;
+    const int64_t d = c * V;
     T* px = x + (b * S + prefix + n) * row_stride + which * (H * Dh) + h * Dh;
     const float* ps = sinT + b * tbs + n * Dh;
     const float* pc = cosT + b * tbs + n * Dh;
-    Vec4<T> x1, x2;
+    VecN<T, V> x1, x2;
     x1.load(px + d);
     x2.load(px + d + half);
-    const float4 s1 = *(const float4*)(ps + d), s2 = *(const float4*)(ps + d + half);
-    const float4 c1 = *(const float4*)(pc + d), c2 = *(const float4*)(pc + d + half);
-    const float s1v[4] = {s1.x, s1.y, s1.z, s1.w}, s2v[4] = {s2.x, s2.y, s2.z, s2.w};
-    const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, c2v[4] = {c2.x, c2.y, c2.z, c2.w};
-    Vec4<T> o1, o2;
+    float s1v[V], s2v[V], c1v[V], c2v[V];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int q = 0; q < V; q += 4) {
+      *(float4*)(s1v + q) = *(const float4*)(ps + d + q);
+      *(float4*)(s2v + q) = *(const float4*)(ps + d + half + q);
+      *(float4*)(c1v + q) = *(const float4*)(pc + d + q);
+      *(float4*)(c2v + q) = *(const float4*)(pc + d + half + q);
+    }
+    VecN<T, V> o1, o2;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
       const float a = x1.v[j], bb = x2.v[j];
       if (!inverse) { o1.v[j] = rope_mix(a, c1v[j], -bb, s1v[j], emu); o2.v[j] = rope_mix(bb, c2v[j], a, s2v[j], emu); }
       else { o1.v[j] = rope_mix(a, c1v[j], bb, s2v[j], emu); o2.v[j] = rope_mix(bb, c2v[j], -a, s1v[j], emu); }
@@ -721,9 +726,16 @@ extern "C" int vitk_rope_rows(void* x, int dtype, const float* table, int64_t B,
   hipStream_t st = (hipStream_t)stream;
   // 8- or 16-byte accesses when the halves of a head are 4-element aligned (rows and sections then are, too)
   const bool vec = Dh % 8 == 0 && row_stride % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)table % 16) == 0;
-  const int64_t total = B * (S - prefix) * nsec * H * (vec ? Dh / 8 : Dh / 4);
+  const bool vec8 = vec && dtype == VITK_BF16 && Dh % 16 == 0 && row_stride % 8 == 0;
+  const int64_t total = B * (S - prefix) * nsec * H * (vec8 ? Dh / 16 : vec ? Dh / 8 : Dh / 4);
   if (total == 0) return 0;
   dim3 grid(ew_grid(total)), block(256);
+  if (vec8) {
+    hipLaunchKernelGGL((rope_rows4_k<bf16, 8>), grid, block, 0, st, (bf16*)x, table, B, S, H, Dh, prefix, row_stride, nsec,
+                       inverse, emulate_bf16, per_sample);
+    VITK_LAUNCH_CHECK("rope");
+    return 0;
+  }
   DISPATCH_DTYPE(dtype, T, {
     if (vec)
       hipLaunchKernelGGL((rope_rows4_k<T>), grid, block, 0, st, (T*)x, table, B, S, H, Dh, prefix, row_stride, nsec, inverse,

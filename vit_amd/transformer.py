@@ -6,6 +6,7 @@ torch.randperm exactly like the reference (same generator, same order: attention
 fused into the norm kernel's load and the scaled scatter-add into the out_proj / fc2 GEMM epilogue."""
 from __future__ import annotations
 
+import collections
 from typing import Any, Optional
 
 import torch
@@ -22,6 +23,30 @@ def drop_path_keep_count(batch_size: int, drop_path_rate: float) -> int:
     return max(1, min(batch_size, int(batch_size * (1.0 - drop_path_rate))))
 
 
+_PERMS: "collections.OrderedDict" = collections.OrderedDict()   # (device, seed, offset, n) -> (permutation, offset after the draw)
+
+
+def _randperm(n: int, device: torch.device) -> Tensor:
+    """torch.randperm(n, device=device) on the device's default generator.  On a GPU the draw is a function of the
+    generator's (seed, offset) alone, so a draw from a state seen before (activation checkpointing replays every block's
+    forward from the saved state) returns the permutation made then and moves the generator by the same amount, instead of
+    launching the half-dozen small kernels of a device-side randperm again."""
+    if device.type != "cuda":
+        return torch.randperm(n, device=device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[index]
+    key = (index, gen.initial_seed(), gen.get_offset(), n)
+    hit = _PERMS.get(key)
+    if hit is not None:
+        gen.set_offset(hit[1])
+        return hit[0]
+    perm = torch.randperm(n, device=device)
+    _PERMS[key] = (perm, gen.get_offset())
+    while len(_PERMS) > 512:
+        _PERMS.popitem(last=False)
+    return perm
+
+
 def _select_keep_indices(x: Tensor, drop_path_rate: float, training: bool):
     """Indices of the samples that go through the residual branch, and the merge scale (vit/transformer.py:14-27)."""
     B = x.shape[0]
@@ -30,7 +55,7 @@ def _select_keep_indices(x: Tensor, drop_path_rate: float, training: bool):
     keep = drop_path_keep_count(B, drop_path_rate)
     if keep == B:
         return None, 1.0
-    perm = torch.randperm(B, device=x.device)
+    perm = _randperm(B, x.device)
     idx = perm[:keep]
     idx._vitk_dropped = perm[keep:]   # the samples that pass through unchanged (ops copies only their rows)
     return idx, float(B / keep)

@@ -74,9 +74,12 @@ class BucketedGradAllReduce:
     last one outside it."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group: Optional[dist.ProcessGroup] = None,
-                 bucket_bytes: int = 64 << 20):
+                 bucket_bytes: int = 64 << 20, always_reduce: bool = False):
+        """``always_reduce``: issue the collectives even in a group of one rank (a rehearsal of the multi-rank path on a
+        single GPU: the same launches, side stream and tile scheduling, averaging over one rank)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._reduce = self.world > 1 or (always_reduce and dist.is_initialized())
         plist = [p for p in params if p.requires_grad and p.numel() > 0]
         self.buckets: List[_Bucket] = []
         cur: List[torch.nn.Parameter] = []
@@ -100,7 +103,7 @@ class BucketedGradAllReduce:
                 _SINKS[p.data_ptr()] = (self, b, i)
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
         # the all-reduce kernels hold CUs beside the backward GEMMs: those then draw their tiles dynamically
-        self.dynamic_tiles = self.world > 1 and backend == "nccl"
+        self.dynamic_tiles = self._reduce and backend == "nccl"
         if self.dynamic_tiles:
             from . import kernels as K
 
@@ -147,7 +150,7 @@ class BucketedGradAllReduce:
 
     def _launch(self, b: _Bucket) -> None:
         b.issued = True
-        if self.world > 1:
+        if self._reduce:
             if self._host_staged:
                 b.host = b.flat.cpu()
                 b.work = dist.all_reduce(b.host, op=self._avg, group=self.group, async_op=True)

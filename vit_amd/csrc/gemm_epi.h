@@ -330,10 +330,40 @@ struct Raw8 {   // 8 bf16 as loaded
   }
 };
 __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
-  bf16x8 t;
-#pragma unroll
-  for (int j = 0; j < 8; j++) t[j] = (bf16)v[j];
-  *(bf16x8*)p = t;
+  typedef float f32x8_t __attribute__((ext_vector_type(8)));
+  const f32x8_t f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  *(bf16x8*)p = __builtin_convertvector(f, bf16x8);   // four v_cvt_pk_bf16_f32
+}
+
+// ---- two values per instruction --------------------------------------------------------------------------------
+// The 8-column GLU epilogues are bound by vector-instruction issue (a 256 x 256 DGLU tile costs 40 k cycles of
+// arithmetic with its loads and stores compiled out), and gfx950 multiplies, adds and fmas two fp32 values in one
+// v_pk_* instruction for the issue cost of one.  The sigmoid-gated activations are therefore written on pairs; every
+// operation is the scalar one of act_apply_t / act_grad_t on each half, so the values are the same.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) {
+  f32x2 r;
+  r.x = __builtin_bit_cast(float, w << 16);
+  r.y = __builtin_bit_cast(float, w & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) {   // one v_cvt_pk_bf16_f32 (element-wise casts give one per value)
+  typedef __attribute__((ext_vector_type(2))) bf16 bf16x2_t;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ f32x2 round_bf16x2(f32x2 v) { return unpack_bf16x2(pack_bf16x2(v)); }
+template <int ACT> constexpr bool act_is_sigmoid_gate() { return ACT == VITK_ACT_SILU || ACT == VITK_ACT_OPENSWIGLU; }
+template <int ACT> __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {   // fast_sigmoid(x, a) on both halves
+  constexpr float a = ACT == VITK_ACT_SILU ? 1.f : 1.702f;
+  const f32x2 t = x * (-1.44269504088896340736f * a);
+  f32x2 d;
+  d.x = __builtin_amdgcn_exp2f(t.x);
+  d.y = __builtin_amdgcn_exp2f(t.y);
+  d = 1.f + d;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return r;
 }
 
 // GLU forward, 8 pairs: lin[8] = fc1 columns f..f+7, glu[8] = columns F+f..F+f+7 of row m (see epi_glu)
@@ -347,9 +377,10 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, flo
   store8((TI*)e.aux + m * e.N + F + f, glu);
   float o[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    lin[j] = round_as<TI>(lin[j]);
-    glu[j] = round_as<TI>(glu[j]);
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 rl = round_bf16x2(f32x2{lin[j], lin[j + 1]}), rg = round_bf16x2(f32x2{glu[j], glu[j + 1]});
+    lin[j] = rl.x; lin[j + 1] = rl.y;
+    glu[j] = rg.x; glu[j + 1] = rg.y;
   }
   if (e.use_limit || e.use_extra) {   // off in the usual configuration: a real (uniform) branch, not selects per element
     asm volatile("" ::: "memory");
@@ -360,8 +391,18 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, flo
     }
   }
   ACT_SWITCH(e.act, ACT, {
-_Pragma("unroll")
-    for (int j = 0; j < 8; j++) o[j] = round_as<TI>(act_apply_t<ACT>(glu[j])) * lin[j];
+    if constexpr (act_is_sigmoid_gate<ACT>()) {
+      _Pragma("unroll")
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2 g = {glu[j], glu[j + 1]}, l = {lin[j], lin[j + 1]};
+        const f32x2 r = round_bf16x2(g * sigmoid2<ACT>(g)) * l;
+        o[j] = r.x;
+        o[j + 1] = r.y;
+      }
+    } else {
+      _Pragma("unroll")
+      for (int j = 0; j < 8; j++) o[j] = round_as<TI>(act_apply_t<ACT>(glu[j])) * lin[j];
+    }
   });
   if (e.thr) {
 #pragma unroll
@@ -380,7 +421,12 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, fl
   for (int j = 0; j < 8; j++) {
     pl[j] = pa.get(j);
     pg[j] = pb.get(j);
-    v[j] = round_as<TI>(v[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 r = round_bf16x2(f32x2{v[j], v[j + 1]});
+    v[j] = r.x;
+    v[j + 1] = r.y;
   }
   if (e.thr) {   // one uniform branch for the vector, not one per element
 #pragma unroll
@@ -407,10 +453,25 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, fl
     }
   }
   ACT_SWITCH(e.act, ACT, {
-    _Pragma("unroll")
-    for (int j = 0; j < 8; j++) {
-      dl[j] *= round_as<TI>(act_apply_t<ACT>(pg[j]));
-      dg[j] *= pl[j] * act_grad_t<ACT>(pg[j]);
+    if constexpr (act_is_sigmoid_gate<ACT>()) {
+      constexpr float a = ACT == VITK_ACT_SILU ? 1.f : 1.702f;
+      _Pragma("unroll")
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2 g = {pg[j], pg[j + 1]}, l = {pl[j], pl[j + 1]};
+        f32x2 vl = {dl[j], dl[j + 1]}, vg = {dg[j], dg[j + 1]};
+        const f32x2 sg = sigmoid2<ACT>(g);
+        vl *= round_bf16x2(g * sg);                              // act_apply_t
+        const f32x2 one_minus = sg * -1.f + 1.f;                 // 1 - s as one packed fma (exact: a single rounding)
+        vg *= l * (sg * (1.f + (a * g) * one_minus));            // act_grad_t
+        dl[j] = vl.x; dl[j + 1] = vl.y;
+        dg[j] = vg.x; dg[j + 1] = vg.y;
+      }
+    } else {
+      _Pragma("unroll")
+      for (int j = 0; j < 8; j++) {
+        dl[j] *= round_as<TI>(act_apply_t<ACT>(pg[j]));
+        dg[j] *= pl[j] * act_grad_t<ACT>(pg[j]);
+      }
     }
   });
   store8((TI*)e.out + m * e.ldo + n, dl);

@@ -335,6 +335,13 @@ __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
   *(bf16x8*)p = __builtin_convertvector(f, bf16x8);   // four v_cvt_pk_bf16_f32
 }
 
+// Element offsets of a lane's 8 columns in one row of the output and of the saved pre-activations.  slab_finish forms them
+// once per slab (one 64-bit multiply each) and moves them on by whole rows with scalar arithmetic; a 64-bit multiply per
+// row and per pointer is several quarter-rate vector instructions in epilogues that are bound by vector issue.
+struct RowOff {
+  int64_t out, aux;
+};
+
 // ---- two values per instruction --------------------------------------------------------------------------------
 // The 8-column GLU epilogues are bound by vector-instruction issue (a 256 x 256 DGLU tile costs 40 k cycles of
 // arithmetic with its loads and stores compiled out), and gfx950 multiplies, adds and fmas two fp32 values in one
@@ -367,14 +374,14 @@ template <int ACT> __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {   // fas
 }
 
 // GLU forward, 8 pairs: lin[8] = fc1 columns f..f+7, glu[8] = columns F+f..F+f+7 of row m (see epi_glu)
-__device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, float (&lin)[8], float (&glu)[8],
+__device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, const RowOff& ro, float (&lin)[8], float (&glu)[8],
                                          const float (&bl)[8], const float (&bg)[8]) {
   typedef bf16 TI;
   const int64_t F = e.N / 2;
 #pragma unroll
   for (int j = 0; j < 8; j++) { lin[j] += bl[j]; glu[j] += bg[j]; }
-  store8((TI*)e.aux + m * e.N + f, lin);
-  store8((TI*)e.aux + m * e.N + F + f, glu);
+  store8((TI*)e.aux + ro.aux, lin);
+  store8((TI*)e.aux + ro.aux + F, glu);
   float o[8];
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
@@ -409,11 +416,12 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, flo
     for (int j = 0; j < 8; j++)
       o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + f + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
   }
-  store8((TI*)e.out + m * e.ldo + f, o);
+  store8((TI*)e.out + ro.out, o);
 }
 
 // DGLU, 8 columns: v = dh[m, n..n+7]; pa / pb = saved linear / gate pre-activations (see EpiVec, EPI_DGLU)
-__device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, float (&v)[8], const Raw8& pa, const Raw8& pb) {
+__device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, const RowOff& ro, float (&v)[8], const Raw8& pa,
+                                          const Raw8& pb) {
   typedef bf16 TI;
   const int64_t F = e.N;
   float dl[8], dg[8], pl[8], pg[8];
@@ -474,8 +482,8 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, fl
       }
     }
   });
-  store8((TI*)e.out + m * e.ldo + n, dl);
-  store8((TI*)e.out + m * e.ldo + F + n, dg);
+  store8((TI*)e.out + ro.out, dl);
+  store8((TI*)e.out + ro.out + F, dg);
 }
 
 // RESIDUAL on a bf16 stream, 8 columns: v = linear output (bias added) of row m; res = the residual row `row`, columns
@@ -503,9 +511,9 @@ __device__ __forceinline__ void epi_res8(const Epi& e, int64_t m, int64_t row, i
 }
 
 // ACT, 8 columns: v = fc1 output (bias added) of row m, columns n..n+7 (see EpiVec, EPI_ACT)
-__device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, float (&v)[8]) {
+__device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, const RowOff& ro, float (&v)[8]) {
   typedef bf16 TI;
-  store8((TI*)e.aux + m * e.N + n, v);
+  store8((TI*)e.aux + ro.aux, v);
   float o[8];
   ACT_SWITCH(e.act, ACT, {
     _Pragma("unroll")
@@ -516,11 +524,11 @@ __device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, flo
     for (int j = 0; j < 8; j++)
       o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
   }
-  store8((TI*)e.out + m * e.ldo + n, o);
+  store8((TI*)e.out + ro.out, o);
 }
 
 // DACT, 8 columns: v = dh[m, n..n+7]; pa = saved pre-activations (see EpiVec, EPI_DACT)
-__device__ __forceinline__ void epi_dact8(const Epi& e, int64_t m, int64_t n, float (&v)[8], const Raw8& pa) {
+__device__ __forceinline__ void epi_dact8(const Epi& e, int64_t m, int64_t n, const RowOff& ro, float (&v)[8], const Raw8& pa) {
   typedef bf16 TI;
 #pragma unroll
   for (int j = 0; j < 8; j++) v[j] = round_as<TI>(v[j]);
@@ -534,7 +542,7 @@ __device__ __forceinline__ void epi_dact8(const Epi& e, int64_t m, int64_t n, fl
     _Pragma("unroll")
     for (int j = 0; j < 8; j++) o[j] = v[j] * act_grad_t<ACT>(pa.get(j));
   });
-  store8((TI*)e.out + m * e.ldo + n, o);
+  store8((TI*)e.out + ro.out, o);
 }
 
 template <int MODE, class TO>
@@ -680,39 +688,44 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
   const int64_t ncol = cols.ncol;
   if (epi_wide<MODE, TO>() && MODE == EPI_GLU) {
     const int cv = lane & 3, rr = lane >> 2;
+    const int64_t out_first = (mbase + rr) * e.ldo + ncol, aux_first = (mbase + rr) * e.N + ncol;
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const int row = it * 16 + rr;
       const int64_t m = mbase + row;
+      const RowOff ro = {out_first + (int64_t)(it * 16) * e.ldo, aux_first + (int64_t)(it * 16) * e.N};
       float lin[8], glu[8];
       *(float4*)lin = *(const float4*)(stg + row * STG_LD + 8 * cv);
       *(float4*)(lin + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
       *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv);
       *(float4*)(glu + 4) = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv + 4);
-      if (m < M && nwave + 8 * cv < N) epi_glu8(e, m, ncol, lin, glu, cols.wb0, cols.wb1);
+      if (m < M && nwave + 8 * cv < N) epi_glu8(e, m, ncol, ro, lin, glu, cols.wb0, cols.wb1);
     }
   } else if (epi_wide<MODE, TO>()) {
     const int cv = lane & 7, rr = lane >> 3;
     const int rope_t0 = MODE == EPI_ROPE ? (int)((mbase + e.m_off) % e.seq) : 0;
+    const int64_t aux_ld = MODE == EPI_DGLU ? 2 * e.N : e.N;   // row length of the saved pre-activations
+    const int64_t out_first = (mbase + rr) * e.ldo + ncol, aux_first = (mbase + rr) * aux_ld + ncol;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
       const int row = it * 8 + rr;
       const int64_t m = mbase + row;
+      const RowOff ro = {out_first + (int64_t)(it * 8) * e.ldo, aux_first + (int64_t)(it * 8) * aux_ld};
       float v[8];
       *(float4*)v = *(const float4*)(stg + row * STG_LD + 8 * cv);
       *(float4*)(v + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
       if (MODE == EPI_DGLU && it < 3 && m + 8 < M && ncol < N) {   // the next row's pre-activations, one step ahead
-        pre.wa[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * 2 * e.N + ncol);
-        pre.wb[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * 2 * e.N + e.N + ncol);
+        pre.wa[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld);
+        pre.wb[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld + e.N);
       }
-      if (MODE == EPI_DACT && it < 3 && m + 8 < M && ncol < N) pre.wa[(it + 1) & 1].load((const bf16*)e.aux + (m + 8) * e.N + ncol);
+      if (MODE == EPI_DACT && it < 3 && m + 8 < M && ncol < N) pre.wa[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld);
       if (m < M && ncol < N) {
-        if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, v, pre.wa[it & 1], pre.wb[it & 1]);
-        else if (MODE == EPI_DACT) epi_dact8(e, m, ncol, v, pre.wa[it & 1]);
+        if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, ro, v, pre.wa[it & 1], pre.wb[it & 1]);
+        else if (MODE == EPI_DACT) epi_dact8(e, m, ncol, ro, v, pre.wa[it & 1]);
         else if (MODE == EPI_ACT) {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
-          epi_act8(e, m, ncol, v);
+          epi_act8(e, m, ncol, ro, v);
         } else if (MODE == VITK_EPI_RESIDUAL) {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
@@ -782,7 +795,7 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
               for (int j = 0; j < 8; j++) v[j] = rope_mix(v[j], cw[j], sign * u[j], sv[j], e.rope_emu);
             }
           }
-          store8((bf16*)e.out + m * e.ldo + ncol, v);
+          store8((bf16*)e.out + ro.out, v);
         }
       }
     }

@@ -129,3 +129,57 @@ def test_single_process_is_a_no_op():
     (p * 3).sum().backward()
     red.finish()
     assert torch.all(p.grad == 3)
+
+
+def _one_rank_worker(port: int, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from vit_amd.ddp import BucketedGradAllReduce
+
+        params = [torch.nn.Parameter(torch.randn(n)) for n in (300, 7, 2000)]
+        quiet = BucketedGradAllReduce(params, bucket_bytes=1024 * 4)
+        assert not quiet._reduce                       # one rank: no collective unless asked for
+        quiet.remove()
+        red = BucketedGradAllReduce(params, bucket_bytes=1024 * 4, always_reduce=True)
+        assert red._reduce and len(red.buckets) >= 2
+        issued = []
+        real = dist.all_reduce
+
+        def counting(t, *a, **k):
+            issued.append(t.numel())
+            return real(t, *a, **k)
+
+        dist.all_reduce = counting
+        try:
+            for step in range(2):
+                for p in params:
+                    p.grad = None
+                sum((i + 1.5 + step) * p.sum() for i, p in enumerate(params)).backward()
+                red.finish()
+                for i, p in enumerate(params):   # the average over one rank is the gradient itself
+                    assert torch.equal(p.grad, torch.full_like(p, i + 1.5 + step)), (step, i)
+            assert len(issued) == 2 * len(red.buckets), issued   # every bucket went through the collective, every step
+        finally:
+            dist.all_reduce = real
+        red.remove()
+        q.put("ok")
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put(repr(e) + traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_always_reduce_runs_the_collectives_in_a_group_of_one():
+    """The rehearsal mode of the reducer (tools/rehearse_ddp_one_rank.py runs it on RCCL): a one-rank group still issues
+    one all-reduce per bucket and step, and the gradients come back unchanged."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert res == "ok", res

@@ -11,11 +11,11 @@ gl = 2 if mode in ("dglu", "glu") else 1
 a, w, aux = rnd(M, D), rnd(D, F), rnd(M, gl * F)
 out = torch.empty(M, gl * F, device="cuda", dtype=torch.bfloat16)
 epi = L.EPI_DGLU if mode == "dglu" else L.EPI_DACT
-run = lambda: K.gemm(a, w, trans_a=False, trans_b=True, M=M, N=F, K=D, out=out, aux=aux, epilogue=epi, act=1, ldo=gl * F)
+run = lambda: K.gemm(a, w, trans_a=False, trans_b=True, M=M, N=F, K=D, out=out, aux=aux, epilogue=epi, act=int(os.environ.get("ACT", "1")), ldo=gl * F)
 if mode == "glu":   # the forward: fc1 + bias + gated activation, pre-activations kept
     w1, b1, h = rnd(2 * F, D), rnd(2 * F), torch.empty(M, F, device="cuda", dtype=torch.bfloat16)
     out = h
-    run = lambda: K.gemm(a, w1, trans_a=False, trans_b=False, M=M, N=2 * F, K=D, out=h, aux=aux, bias=b1, epilogue=L.EPI_GLU, act=1)
+    run = lambda: K.gemm(a, w1, trans_a=False, trans_b=False, M=M, N=2 * F, K=D, out=h, aux=aux, bias=b1, epilogue=L.EPI_GLU, act=int(os.environ.get("ACT", "1")))
 for _ in range(5): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -39,9 +39,17 @@ WORKLOADS = {
     # BASELINE config 1: the reference's own CPU-runnable case, forward only (plumbing; fp32 takes the portable kernels)
     "vit_s16_224_fp32_fwd": dict(
         cfg=dict(in_channels=3, patch_size=(16, 16), img_size=(224, 224), depth=12, hidden_size=384, ffn_hidden_size=1536,
-                 num_attention_heads=6, hidden_dropout=0.0, attention_dropout=0.0, activation="gelu", pos_enc="fourier",
-                 dtype="float32"),
+                 num_attention_heads=6, hidden_dropout=0.0, attention_dropout=0.0, activation="srelu", pos_enc="rope",
+                 dtype="float32"),   # activation / positions: the reference's defaults (vit/vit.py:83,87)
         autocast=False, batch=8, forward_only=True),
+    # the README's training configuration (README.md:28-48) on the headline shape: hidden / attention dropout 0.1, layer
+    # scale 1e-5, normalised patch embedding.  Its drop_path_rate is left out: under autocast the reference's own
+    # index_add of the bf16 branch into the fp32 stream raises, so that combination does not run there either.
+    "vit_b14_224_readme_dropout": dict(
+        cfg=dict(in_channels=3, patch_size=(14, 14), img_size=(224, 224), depth=12, hidden_size=768, ffn_hidden_size=3072,
+                 num_attention_heads=12, hidden_dropout=0.1, attention_dropout=0.1, activation="swiglu", pos_enc="fourier",
+                 num_register_tokens=16, patch_embed_normalization=True, layer_scale=1e-5, dtype="float32"),
+        autocast=True, batch=256),
     # BASELINE config 3 / 4 / 5 shapes (secondary; pure bf16 parameters)
     "vit_l16_384_srelu_rope": dict(
         cfg=dict(in_channels=3, patch_size=(16, 16), img_size=(384, 384), depth=24, hidden_size=1024, ffn_hidden_size=4096,
@@ -275,7 +283,7 @@ def main() -> None:
         fpi = flops_per_image(c)
         traffic, mfma_util = counter_summary(args.workload, B)
         rec = {
-            "metric": "train images/sec ViT-B/14 224px bf16" if args.workload.startswith("vit_b14") else
+            "metric": "train images/sec ViT-B/14 224px bf16" if args.workload == "vit_b14_224_swiglu_reg16_fourier" else
                       f"{'forward' if fwd_only else 'train'} images/sec {args.workload}",
             "value": round(imgs, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -294,7 +302,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w)
-            if args.workload.startswith("vit_b14"):   # the headline run also times the reference's own CPU case
+            if args.workload == "vit_b14_224_swiglu_reg16_fourier":   # the headline run also times the reference's own CPU case
                 rec["cpu_baseline_config1"] = cpu_baseline_config1()
         print(json.dumps(rec), flush=True)
     if world > 1:

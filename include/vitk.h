@@ -228,7 +228,9 @@ int vitk_colsum(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, c
  * harnesses that forbid hipMalloc).  The per-chunk partial sums go to a device array built into the library (8 MiB per
  * GPU, held until the process ends), so N is limited to 8192 columns; larger N is rejected with an error.  All calls on
  * one GPU share that array: calls that overlap on one GPU (different streams) race -- serialise them.  The first call on
- * a device looks up the array's address (no allocation); make that call outside graph capture. */
+ * a device looks up the array's address (no allocation); make that call outside graph capture.  The array used is the
+ * CURRENT device's: the current device must be the one that owns `stream` and the operands, and a call whose `out`
+ * lives on another device is rejected. */
 int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const int64_t* a_idx, const void* b, int b_dtype, int64_t ldb,
                        void* out, int out_dtype, int64_t rows, int64_t N, float scale, void* stream);
 

@@ -97,6 +97,37 @@ def _worker(rank: int, world: int, port: int, q):
         assert torch.allclose(target.grad, torch.full_like(target, expect)), ("sink", target.grad[:3], expect)
         with red.no_sync():
             assert grad_sink(target.data_ptr(), target.shape, target.dtype) is None   # accumulation: no sinks
+
+        class MaybeSinkFn(torch.autograd.Function):   # as the product's backward: the slice if offered, else a new tensor
+            @staticmethod
+            def forward(ctx, p, c):
+                ctx.c, ctx.ptr = c, p.data_ptr()
+                return p.detach() * c
+
+            @staticmethod
+            def backward(ctx, g):
+                out = grad_sink(ctx.ptr, g.shape, g.dtype)
+                out = torch.empty_like(g) if out is None else out
+                torch.mul(g, ctx.c, out=out)
+                return out, None
+
+        # .grad kept between steps and zeroed in place (zero_grad(set_to_none=False)): it still is the bucket slice of the
+        # last step, so the slice must not be offered again (the kernel's result would then be added to itself)
+        assert target.grad.data_ptr() == slot.data_ptr()
+        for p in params + [unused]:
+            if p.grad is not None:
+                p.grad.zero_()
+        (MaybeSinkFn.apply(target, float(rank + 1)).sum() + sum(p.sum() for p in params if p is not target)).backward()
+        red.finish()
+        assert torch.allclose(target.grad, torch.full_like(target, expect)), ("sink, grad zeroed in place", target.grad[:3], expect)
+        # a micro-batch under no_sync(), then a synchronised step that would take the slice: the sum of both, averaged
+        for p in params + [unused]:
+            p.grad = None
+        with red.no_sync():
+            MaybeSinkFn.apply(target, 10.0).sum().backward()
+        (MaybeSinkFn.apply(target, float(rank + 1)).sum() + sum(p.sum() for p in params if p is not target)).backward()
+        red.finish()
+        assert torch.allclose(target.grad, torch.full_like(target, 10.0 + expect)), ("sink after no_sync", target.grad[:3])
         red.remove()
         assert grad_sink(target.data_ptr(), target.shape, target.dtype) is None
         q.put((rank, "ok"))
@@ -183,3 +214,69 @@ def test_always_reduce_runs_the_collectives_in_a_group_of_one():
     res = q.get(timeout=120)
     p.join(timeout=60)
     assert res == "ok", res
+
+
+def _encoder_worker(rank: int, world: int, port: int, q):
+    """The encoder's own parameter set (prefix tokens, patch embedding, Fourier positions, two blocks, output norm)
+    under the reducer, with gradient accumulation: the graph is the CPU oracle's forward over nn.Parameters (the HIP
+    path needs a GPU), the reducer and its hooks are the product's."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import vit_oracle as O
+        from vit_amd.ddp import BucketedGradAllReduce
+
+        cfg = O.OracleConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=2, hidden_size=64,
+                             ffn_hidden_size=128, num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0,
+                             activation="swiglu", pos_enc="fourier", num_register_tokens=2, dtype=torch.float32)
+        sd = O.randomize_state(O.init_state(cfg, seed=0), seed=1)
+        params = {k: torch.nn.Parameter(v.clone(), requires_grad=v.is_floating_point() and v.numel() > 0 and k != "rope.periods")
+                  for k, v in sd.items()}
+        x = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+        red = BucketedGradAllReduce(params.values(), bucket_bytes=16 << 10)
+        assert len(red.buckets) >= 4, len(red.buckets)
+
+        def loss_of(batch):
+            return O.vit_forward(cfg, params, batch, training=True).float().square().mean()
+
+        mine = x[rank * 4:(rank + 1) * 4]
+        for step in range(2):   # second step: re-armed buckets, .grad still pointing into them when set_to_none is False
+            for p_ in params.values():
+                if step == 0:
+                    p_.grad = None
+                elif p_.grad is not None:
+                    p_.grad.zero_()
+            with red.no_sync():
+                loss_of(mine[:2]).backward()      # micro-batch 1: accumulates locally, nothing is exchanged
+            loss_of(mine[2:]).backward()          # micro-batch 2: hooks fire, buckets go out
+            red.finish()
+            got = {k: p_.grad.clone() for k, p_ in params.items() if p_.requires_grad}
+            # one process, the whole batch: each micro-batch loss is a mean over 2 of the 8 samples, the reducer averages
+            # over 2 ranks, so the result is 2 x the gradient of the mean over all 8
+            ref = {k: v.detach().clone().requires_grad_(p_.requires_grad) for (k, v), p_ in zip(sd.items(), params.values())}
+            O.vit_forward(cfg, ref, x, training=True).float().square().mean().backward()
+            for k, g in got.items():
+                want = 2.0 * ref[k].grad
+                assert torch.allclose(g, want, rtol=1e-4, atol=1e-6 + 1e-4 * want.abs().max().item()), (step, k)
+        red.remove()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_encoder_gradient_accumulation_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_encoder_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results

@@ -591,3 +591,47 @@ def test_drop_path_subset_replayed_from_a_saved_generator_state_is_the_same_draw
     assert torch.equal(after_first, after) and torch.equal(after_second, after)
     third, _ = T._select_keep_indices(x, 0.25, True)      # the generator has moved on: a new draw
     assert len(T._PERMS) == 2
+
+
+def test_parameter_written_through_data_needs_the_copies_cleared_and_the_guards_do_it():
+    """Under autocast the host keeps bf16 copies of fp32 parameters, keyed on version counter and address; a write through
+    ``.data`` changes neither.  ``clear_param_copies()``, an optimizer step and a train() / eval() switch each drop the
+    copies, and the debugging mode raises on a stale one."""
+    from vit_amd import ops
+
+    cfg = ViTConfig(in_channels=3, patch_size=(8, 8), img_size=(32, 32), depth=1, hidden_size=64, ffn_hidden_size=128,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="fourier",
+                    dtype=torch.float32)
+    model = cfg.instantiate(device=DEV).eval()
+    with torch.no_grad():
+        model.blocks[0].mlp.fc2.weight.normal_(std=0.05)
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+
+    def run():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(x).dense_features.float().clone()
+
+    w = model.blocks[0].mlp.fc1.weight
+    base = run()
+    w.data.mul_(2.0)                          # no version bump, same address
+    ops.clear_param_copies()
+    changed = run()
+    assert not torch.allclose(changed, base)
+    w.data.mul_(0.5)
+    model.train()                             # a mode switch drops the copies as well
+    model.eval()
+    close(run(), base, 1e-6, "after train()/eval()")
+    w.data.mul_(2.0)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1, device=DEV))], lr=0.1)
+    opt.param_groups[0]["params"][0].grad = torch.zeros(1, device=DEV)
+    opt.step()                                # any optimizer's step: the global post-step hook
+    close(run(), changed, 1e-6, "after optimizer step")
+    old = ops._PARAM_CACHE_CHECK
+    ops._PARAM_CACHE_CHECK = True
+    try:
+        w.data.mul_(0.5)
+        with pytest.raises(RuntimeError, match="stale"):
+            run()
+    finally:
+        ops._PARAM_CACHE_CHECK = old
+        ops.clear_param_copies()

@@ -2,7 +2,7 @@
 
     python tools/pmc_summary.py gpurun_out/pmc profiles/r02_pmc_summary --steps 5
 
-reads <dir>/{mfma,fetch,write}/*_counter_collection.csv (+ the kernel trace of the mfma pass) and writes
+reads <dir>/{mfma,fetch,write,l2}/*_counter_collection.csv (+ the kernel trace of the mfma pass) and writes
 <out>.csv (one row per kernel: calls, summed duration, raw counter sums, derived figures) and <out>.json (the same
 rows, the whole-run totals, the formulas, and an identification of the build the passes ran on).
 
@@ -15,6 +15,7 @@ Derived figures (gfx950):
   clock_ghz      = GRBM_GUI_ACTIVE / 8 / duration       (reads high on dispatches shorter than ~0.3 ms)
   read_bytes     = 2 * FETCH_SIZE * 1024   (FETCH_SIZE tallies the 128-byte requests of wide reads at 64 bytes)
   write_bytes    = WRITE_SIZE * 1024
+  l2_hit_rate    = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)   (all eight per-XCD L2s together; the l2 pass is optional)
 """
 import argparse
 import collections
@@ -112,9 +113,10 @@ def main():
                     "<raw-dir>/{mfma,fetch,write}_counter_rows.csv")
     a = ap.parse_args()
 
+    PASSES = [n for n in ("mfma", "fetch", "write", "l2") if os.path.isdir(os.path.join(a.pmc_dir, n))]
     if a.raw_dir:   # the counter rows themselves, so that every derived figure can be recomputed from the repository alone
         os.makedirs(a.raw_dir, exist_ok=True)
-        for pass_name in ("mfma", "fetch", "write"):
+        for pass_name in PASSES:
             with open(find(os.path.join(a.pmc_dir, pass_name), "counter_collection.csv"), newline="") as f, \
                     open(os.path.join(a.raw_dir, f"{pass_name}_counter_rows.csv"), "w", newline="") as o:
                 w = csv.writer(o)
@@ -126,7 +128,9 @@ def main():
 
     rows = collections.defaultdict(lambda: collections.defaultdict(float))
     for pass_name, counters in (("mfma", ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")),
-                                ("fetch", ("FETCH_SIZE",)), ("write", ("WRITE_SIZE",))):
+                                ("fetch", ("FETCH_SIZE",)), ("write", ("WRITE_SIZE",)), ("l2", ("TCC_HIT_sum", "TCC_MISS_sum"))):
+        if pass_name not in PASSES:
+            continue
         vals, meta = read_counters(find(os.path.join(a.pmc_dir, pass_name), "counter_collection.csv"))
         for d, (kern, t0, t1) in meta.items():
             r = rows[kern]
@@ -147,6 +151,8 @@ def main():
             "clock_ghz": round(cyc / ns, 3) if ns else 0.0,
             "read_bytes_per_call": round(2 * r["FETCH_SIZE"] * 1024 / max(r["calls_fetch"], 1)),
             "write_bytes_per_call": round(r["WRITE_SIZE"] * 1024 / max(r["calls_write"], 1)),
+            "TCC_HIT_sum": r["TCC_HIT_sum"], "TCC_MISS_sum": r["TCC_MISS_sum"],
+            "l2_hit_rate": round(r["TCC_HIT_sum"] / (r["TCC_HIT_sum"] + r["TCC_MISS_sum"]), 4) if r["TCC_HIT_sum"] + r["TCC_MISS_sum"] else None,
             "hbm_side_gbps": round((2 * r["FETCH_SIZE"] * 1024 / max(r["ns_fetch"], 1) + r["WRITE_SIZE"] * 1024 / max(r["ns_write"], 1)), 1),
         })
     out.sort(key=lambda x: -x["ms_per_step"])
@@ -162,15 +168,16 @@ def main():
     except OSError:
         commit, dirty = "", False
     summary = {
-        "command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- {a.command}  (three passes: "
-                   "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE; tools/pmc_collect.sh)",
+        "command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- {a.command}  (one pass per counter group: "
+                   "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum; tools/pmc_collect.sh)",
         "steps_in_run": a.steps,
         "build": {"git_commit": commit, "tree_modified_since_commit": dirty,
                   "libvitk_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None},
         "formulas": {"mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)",
                      "clock_ghz": "GRBM_GUI_ACTIVE / 8 / duration_ns",
                      "read_bytes": "2 * FETCH_SIZE * 1024 (gfx950 tallies 128-byte read requests at 64 bytes)",
-                     "write_bytes": "WRITE_SIZE * 1024"},
+                     "write_bytes": "WRITE_SIZE * 1024",
+                     "l2_hit_rate": "TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)"},
         "whole_run": {"kernel_ms_per_step": round(tot_ns / a.steps / 1e6, 3),
                       "mfma_busy_frac": round(tot_busy / (tot_cyc * CUS * 4), 4) if tot_cyc else 0.0,
                       "mean_clock_ghz": round(tot_cyc / tot_ns, 3) if tot_ns else 0.0},
@@ -186,7 +193,7 @@ def main():
     for r in out[:14]:
         print(f'{r["ms_per_step"]:8.3f} ms/step {r["calls_per_step"]:6.1f} calls  mfma_busy {r["mfma_busy_frac"]:.3f}  '
               f'{r["clock_ghz"]:.2f} GHz  rd {r["read_bytes_per_call"] / 1e6:8.1f} MB wr {r["write_bytes_per_call"] / 1e6:8.1f} MB  '
-              f'{r["kernel"][:60]}  {r["role"]}')
+              f'L2 hit {r["l2_hit_rate"] if r["l2_hit_rate"] is not None else float("nan"):.3f}  {r["kernel"][:60]}  {r["role"]}')
 
 
 if __name__ == "__main__":

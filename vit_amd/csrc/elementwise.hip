@@ -332,6 +332,19 @@ extern "C" int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const
   VITK_REQUIRE(a && out && rows >= 0 && N > 0, "colsum_static: bad arguments");
   VITK_REQUIRE(N <= COLSUM_STATIC_MAX_N, "colsum_static: N=%lld exceeds the built-in scratch (at most %lld columns); use vitk_colsum "
                "with a caller workspace", (long long)N, (long long)COLSUM_STATIC_MAX_N);
+  // The scratch used is the CURRENT device's copy, so the current device has to be the one that owns the operands (and
+  // the stream): a kernel on another GPU would write through an address that means nothing there.
+  {
+    int cur = -1;
+    hipPointerAttribute_t at;
+    VITK_REQUIRE(hipGetDevice(&cur) == hipSuccess, "colsum_static: cannot identify the current device");
+    if (hipPointerGetAttributes(&at, out) == hipSuccess) {
+      VITK_REQUIRE(at.device == cur, "colsum_static: `out` lives on device %d but device %d is current; make the operands' "
+                   "device current before the call", at.device, cur);
+    } else {
+      (void)hipGetLastError();   // not a pointer the runtime knows: the launch itself will report it
+    }
+  }
   float* ws = nullptr;
   if (int rc = scratch_for_current_device(&ws)) return rc;
   // every chunk row that the second pass reads is written whole by the first pass: nothing has to start at zero

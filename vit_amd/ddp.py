@@ -38,6 +38,12 @@ def grad_sink(param_ptr: int, shape, dtype: torch.dtype) -> Optional[torch.Tenso
     p = b.params[i]
     if tuple(p.shape) != tuple(shape) or p.dtype != dtype:
         return None
+    # A gradient that is already there (zero_grad(set_to_none=False), or micro-batches accumulated under no_sync())
+    # makes autograd ADD the new one to it.  If the kernel wrote into the slice, that would either add the slice to
+    # itself (p.grad is the slice from the last step: the gradient doubles) or overwrite what was accumulated, so the
+    # slice is only handed out when autograd will adopt it as a fresh .grad.
+    if p.grad is not None:
+        return None
     b.given[i] = True
     return red._view(b, i)
 

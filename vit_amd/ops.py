@@ -87,6 +87,28 @@ _PARAM_CACHE_ON = os.environ.get("VITK_NO_PARAM_CACHE", "") == ""
 def clear_param_copies() -> None:
     """Forget the kept compute-dtype copies: for code that rewrites parameters through ``.data`` (no version bump)."""
     _PARAM_COPIES.clear()
+    _QK_PARAMS.clear()
+
+
+# A write through ``param.data`` (``p.data.mul_()``, EMA weight swaps, some third-party optimizers) changes neither the
+# version counter nor the address, so the kept copies would go stale without an error.  Two guards:
+#   * every optimizer step (torch's global post-step hook) and every train() / eval() switch of a ViT drops the copies,
+#     so the usual places such writes happen in are covered at the cost of one round of casts;
+#   * VITK_CHECK_PARAM_CACHE=1 compares a kept copy with a fresh cast on every use and raises on a difference
+#     (a debugging mode: one extra cast and a device-to-host sync per parameter use).
+_PARAM_CACHE_CHECK = os.environ.get("VITK_CHECK_PARAM_CACHE", "") not in ("", "0")
+
+
+def _drop_copies_after_step(*_a, **_k) -> None:
+    clear_param_copies()
+
+
+try:   # one registration for every optimizer of the process
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_step
+
+    _reg_post_step(_drop_copies_after_step)
+except ImportError:   # pragma: no cover - torch without global optimizer hooks
+    pass
 
 
 def _cast_param(t: Optional[Tensor], dtype: torch.dtype, make=None) -> Optional[Tensor]:
@@ -99,6 +121,12 @@ def _cast_param(t: Optional[Tensor], dtype: torch.dtype, make=None) -> Optional[
     key = (t._version, t.data_ptr(), dtype, tuple(t.shape))
     ent = _PARAM_COPIES.get(id(t))
     if ent is not None and ent[0]() is t and ent[1] == key:
+        if _PARAM_CACHE_CHECK:
+            fresh = make(t.detach()) if make is not None else t.detach().to(dtype)
+            if not torch.equal(fresh, ent[2]):
+                raise RuntimeError("vit_amd: a cached compute-dtype copy of a parameter is stale: the parameter was changed "
+                                   "without a version bump (a write through .data?); call vit_amd.ops.clear_param_copies() "
+                                   "after such writes or set VITK_NO_PARAM_CACHE=1")
         return ent[2]
     c = make(t.detach()) if make is not None else t.detach().to(dtype).contiguous()
     if not _PARAM_CACHE_ON:

@@ -125,6 +125,13 @@ class ViT(nn.Module):
     def prefix_length(self) -> int:
         return self._config.num_register_tokens
 
+    def train(self, mode: bool = True):
+        """A switch between training and evaluation is where weights get swapped through ``.data`` (EMA copies, loaded
+        checkpoints): the kept compute-dtype copies of the parameters are dropped with it (vit_amd.ops._cast_param)."""
+        if mode != self.training:
+            ops.clear_param_copies()
+        return super().train(mode)
+
     # ---- forward -----------------------------------------------------------------------------------
     def add_prefix_tokens(self, x: Tensor) -> Tensor:
         """[B, N, D] -> [B, n_cls + n_reg + N, D], order cls, register, patches; dtype promotes like torch.cat."""

@@ -139,6 +139,16 @@ typedef struct VitkGemm {
   float* qk_mean;
   float qk_eps;
   int32_t qk_layernorm;
+  /* Tuning knobs of the MFMA kernels; 0 = the library's choice (what production callers pass).
+   *   store_policy  1: the epilogue's 16-byte output stores are plain (their lines stay in the XCD's L2);
+   *                 2: they are written through (sc1: the line is not kept, so a tile's output does not push the operand
+   *                    panels of the neighbouring tiles out of the 4 MiB L2);
+   *                 3: as 2, and the epilogue's read-once rows (saved pre-activations, residual rows) are asked for
+   *                    with the streaming (nt) policy.
+   *   panel_m       row tiles per panel of the tile walk (tiles are walked panel by panel, column tile by column tile
+   *                 inside a panel, so that a panel's A rows stay in L2 across its column tiles). */
+  int32_t store_policy;
+  int32_t panel_m;
 } VitkGemm;
 
 size_t vitk_gemm_workspace_bytes(const VitkGemm* g);

@@ -39,6 +39,7 @@ class VitkGemm(C.Structure):
         ("rope", C.c_void_p), ("rope_width", C.c_int64), ("rope_emulate_bf16", C.c_int32),
         ("qk_norm_weight", C.c_void_p), ("qk_norm_bias", C.c_void_p), ("qk_rstd", C.c_void_p), ("qk_mean", C.c_void_p),
         ("qk_eps", C.c_float), ("qk_layernorm", C.c_int32),
+        ("store_policy", C.c_int32), ("panel_m", C.c_int32),
     ]
 
 

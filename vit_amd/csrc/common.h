@@ -171,6 +171,9 @@ template <int ACT> __device__ __forceinline__ float act_grad_t(float x) {
   const float s = fast_sigmoid(x, 1.702f);
   return s * (1.f + 1.702f * x * (1.f - s));
 }
+#ifdef EXP_ONLY_SILU   // diagnostic build: every fused activation is SiLU (what a single compiled variant costs)
+#define ACT_SWITCH(code, ACT, ...) { constexpr int ACT = VITK_ACT_SILU; __VA_ARGS__; }
+#else
 #define ACT_SWITCH(code, ACT, ...)                                              \
   switch (code) {                                                              \
     case VITK_ACT_RELU: { constexpr int ACT = VITK_ACT_RELU; __VA_ARGS__; } break;   \
@@ -179,5 +182,6 @@ template <int ACT> __device__ __forceinline__ float act_grad_t(float x) {
     case VITK_ACT_SRELU: { constexpr int ACT = VITK_ACT_SRELU; __VA_ARGS__; } break; \
     default: { constexpr int ACT = VITK_ACT_OPENSWIGLU; __VA_ARGS__; } break;        \
   }
+#endif
 
 __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

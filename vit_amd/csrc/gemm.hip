@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A
   const int wm = wid >> 1, wn = wid & 1;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
   int64_t tm, tn, split;
-  tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
+  tile_coords(wg, tiles_m, tiles_n, e.panel_m, tm, tn, split);
   const int64_t m0 = tm * BM, n0 = tn * BN;
   const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
   float rs[2] = {0.f, 0.f};
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
   const int wm = grp, wn = wid & 3;    // wave tile: rows [wm*128, +128), columns [wn*64, +64)
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
   int64_t tm, tn, split;
-  tile_coords(wg, tiles_m, tiles_n, tm, tn, split);
+  tile_coords(wg, tiles_m, tiles_n, e.panel_m, tm, tn, split);
   const int64_t m0 = tm * BM2, n0 = tn * BN2;
   const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -429,7 +429,10 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
                                                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t tiles_m,
                                                        int64_t tiles_n, int64_t klen, Epi e, float* __restrict__ partial,
                                                        unsigned int* __restrict__ ctr) {
-  __shared__ __attribute__((aligned(1024))) char smem[4 * SLOT_B];
+  // the operand ring; the epilogue lays its staging slabs (8 x 8704 B) and, behind them, the operand stream's rings
+  // (8 x STREAM_B) over it
+  constexpr int STREAM_BASE = 8 * 32 * STG_LD * 4;
+  __shared__ __attribute__((aligned(1024))) char smem[(STREAM_BASE + 8 * STREAM_B > 4 * SLOT_B) ? STREAM_BASE + 8 * STREAM_B : 4 * SLOT_B];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;
   STAMP_DECL
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   unsigned int drawn = 0;
   if (dynamic && tid == 0) drawn = __hip_atomic_fetch_add(&ctr[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int64_t tm, tn, split;
-  tile_coords(xcd_remap(xcd + 8 * jt, total_tiles), tiles_m, tiles_n, tm, tn, split);
+  tile_coords(xcd_remap(xcd + 8 * jt, total_tiles), tiles_m, tiles_n, e.panel_m, tm, tn, split);
   const int64_t m0 = tm * BM2, n0 = tn * BN2;
   const int64_t kbeg = split * klen;
   const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
@@ -538,20 +541,35 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
     }
   }
   float* stg = (float*)smem + wid * (32 * STG_LD);
-  SlabPre<MODE, TO> pre;
-  // the four slabs, spelled out: a slab index that is not a compile-time constant would index the accumulator array
-  // dynamically and send all of it to scratch memory (the unroll pragma alone is not honoured for the largest epilogues)
-  auto one_slab = [&](auto slc) {
-    constexpr int sl = decltype(slc)::value;
-    const int64_t mbase = m0 + wm * 128 + sl * 32;
-    slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
-    slab_stage16(stg, acc, sl, lane);
-    slab_finish<MODE, TO>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
+  // the epilogue of the tile, with the activation of a fused epilogue switched on once out here (ACT_DISPATCH)
+  auto run_epilogue = [&](auto actc) {
+    constexpr int ACTC = decltype(actc)::value;
+    if constexpr (epi_streams<MODE, TO>()) {
+      if (e.stream && m0 + BM2 <= M && n0 + BN2 <= N) {   // a whole tile (block-uniform)
+        epilogue_stream16<MODE, TO, ACTC>(e, cols, stg, smem + STREAM_BASE + wid * STREAM_B, acc, m0 + wm * 128, lane);
+        return;
+      }
+    }
+    SlabPre<MODE, TO> pre;
+    // the four slabs, spelled out: a slab index that is not a compile-time constant would index the accumulator array
+    // dynamically and send all of it to scratch memory (the unroll pragma alone is not honoured for the largest epilogues)
+    auto one_slab = [&](auto slc) {
+      constexpr int sl = decltype(slc)::value;
+      const int64_t mbase = m0 + wm * 128 + sl * 32;
+      slab_prefetch<MODE, TO>(e, cols, pre, mbase, M, N, lane);
+      slab_stage16(stg, acc, sl, lane);
+      slab_finish<MODE, TO, ACTC>(e, cols, pre, stg, mbase, n0 + wn * 64, M, N, split, partial, lane);
+    };
+    one_slab(std::integral_constant<int, 0>{});
+    one_slab(std::integral_constant<int, 1>{});
+    one_slab(std::integral_constant<int, 2>{});
+    one_slab(std::integral_constant<int, 3>{});
   };
-  one_slab(std::integral_constant<int, 0>{});
-  one_slab(std::integral_constant<int, 1>{});
-  one_slab(std::integral_constant<int, 2>{});
-  one_slab(std::integral_constant<int, 3>{});
+  if constexpr (MODE == EPI_GLU || MODE == EPI_DGLU || MODE == EPI_ACT || MODE == EPI_DACT) {
+    ACT_SWITCH(e.act, ACT, run_epilogue(std::integral_constant<int, ACT>{}));
+  } else {
+    run_epilogue(std::integral_constant<int, -1>{});
+  }
   STAMP(4)
   if (dynamic && tid == 0) s_next = drawn;
   __syncthreads();   // the staging slabs overlay the ring: done before the next tile's first requests
@@ -655,6 +673,15 @@ static bool mfma_ok(const VitkGemm* g) {
   return g->M > 0 && g->N > 0 && g->K > 0;
 }
 
+// VITK_EPI_STREAM=0 keeps the register-prefetched epilogues on whole tiles too (A/B runs)
+static int epilogue_stream_default() {
+  static const int v = [] {
+    const char* f = getenv("VITK_EPI_STREAM");
+    return f ? atoi(f) : 1;
+  }();
+  return v;
+}
+
 // split the contraction when the output has too few tiles to fill 256 CUs (weight gradients)
 static bool use_tile256(const VitkGemm* g);
 static int pick_splits(const VitkGemm* g) {
@@ -714,6 +741,15 @@ extern "C" size_t vitk_gemm_workspace_bytes(const VitkGemm* g) {
   return g->dynamic_tiles && use_tile256(g) ? (part + 255) / 256 * 256 + 256 : part;   // + the tile counters
 }
 
+// Cache policy of the epilogues' 16-byte output stores (st16): VITK_WT_STORES=0/1 overrides the default (A/B runs).
+static int write_through_default() {
+  static const int v = [] {
+    const char* f = getenv("VITK_WT_STORES");
+    return f ? atoi(f) : 0;
+  }();
+  return v;
+}
+
 static Epi make_epi(const VitkGemm* g) {
   Epi e;
   e.out = g->out; e.bias = g->bias; e.res = g->res; e.gamma = g->gamma; e.row_idx = g->row_idx; e.aux = g->aux;
@@ -727,6 +763,10 @@ static Epi make_epi(const VitkGemm* g) {
   e.rope = g->rope; e.rope_width = g->rope_width; e.rope_emu = g->rope_emulate_bf16;
   e.qk_w = g->qk_norm_weight; e.qk_b = g->qk_norm_bias; e.qk_rstd = g->qk_rstd; e.qk_mean = g->qk_mean;
   e.qk_eps = g->qk_eps; e.qk_ln = g->qk_layernorm; e.rows_total = g->M;
+  e.wt = g->store_policy >= 2 || (g->store_policy == 0 && write_through_default());
+  e.ntl = g->store_policy == 3;
+  e.stream = !g->row_idx && epilogue_stream_default();
+  e.panel_m = g->panel_m > 0 ? g->panel_m : PANEL_M;
   return e;
 }
 
@@ -751,7 +791,10 @@ static bool use_tile256(const VitkGemm* g) {
   if (g->algo == 4) return false;
   // measured on MI355X (ViT-B shapes): the 256^2 tile wins once the output is wide or the contraction long;
   // narrow, short problems (N = K = 768) keep more CUs busy with 128^2 tiles
-  return g->M >= 512 && g->N >= 512 && (g->N >= 1024 || g->K >= 2048);
+  if (g->M >= 512 && g->N >= 512 && (g->N >= 1024 || g->K >= 2048)) return true;
+  // the residual epilogue with its operand stream (whole tiles, no row gather) costs the large tile less than three
+  // small workgroups per CU gain by overlapping their epilogues: out_proj (N = K = 768) 0.18 against 0.20 ms
+  return g->epilogue == VITK_EPI_RESIDUAL && !g->row_idx && epilogue_stream_default() && g->M >= 2048 && g->N >= 512 && g->N % 256 == 0;
 }
 
 static int64_t cu_count() {
@@ -890,12 +933,14 @@ static int launch_mfma(const VitkGemm* g, const Epi& e, hipStream_t st) {
     }
   }
   else if (g->epilogue == VITK_EPI_PATCH) launch_mfma_one<false, false, VITK_EPI_PATCH, TO>(g, e, 1, klen, nullptr, st);
-  else if (g->epilogue == VITK_EPI_ACT) launch_mfma_one<false, false, VITK_EPI_ACT, TO>(g, e, 1, klen, nullptr, st);
-  else if (g->epilogue == VITK_EPI_GLU) launch_mfma_one<false, false, VITK_EPI_GLU, TO>(g, e, 1, klen, nullptr, st);
-  else if (g->epilogue == VITK_EPI_DACT) launch_mfma_one<false, true, VITK_EPI_DACT, TO>(g, e, 1, klen, nullptr, st);
-  else if (g->epilogue == VITK_EPI_DGLU) launch_mfma_one<false, true, VITK_EPI_DGLU, TO>(g, e, 1, klen, nullptr, st);
-  else if (g->epilogue == VITK_EPI_ROPE) {
-    if constexpr (sizeof(TO) == 2) launch_mfma_one<false, false, VITK_EPI_ROPE, TO>(g, e, 1, klen, nullptr, st);
+  else if (g->epilogue >= VITK_EPI_ACT && g->epilogue <= VITK_EPI_ROPE) {   // bf16 outputs only (checked by vitk_gemm)
+    if constexpr (sizeof(TO) == 2) {
+      if (g->epilogue == VITK_EPI_ACT) launch_mfma_one<false, false, VITK_EPI_ACT, TO>(g, e, 1, klen, nullptr, st);
+      else if (g->epilogue == VITK_EPI_GLU) launch_mfma_one<false, false, VITK_EPI_GLU, TO>(g, e, 1, klen, nullptr, st);
+      else if (g->epilogue == VITK_EPI_DACT) launch_mfma_one<false, true, VITK_EPI_DACT, TO>(g, e, 1, klen, nullptr, st);
+      else if (g->epilogue == VITK_EPI_DGLU) launch_mfma_one<false, true, VITK_EPI_DGLU, TO>(g, e, 1, klen, nullptr, st);
+      else launch_mfma_one<false, false, VITK_EPI_ROPE, TO>(g, e, 1, klen, nullptr, st);
+    }
   }
   else if (!g->trans_a && !g->trans_b) launch_mfma_layout<false, false, TO>(g, e, splits, klen, st);
   else if (!g->trans_a && g->trans_b) launch_mfma_layout<false, true, TO>(g, e, splits, klen, st);

@@ -3,6 +3,16 @@
 #pragma once
 #include "common.h"
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+// A 16-byte store of write-once output.  A plain store leaves its line in the XCD's 4 MiB L2, where a tile's 128-512 KiB of
+// output push out the operand panels that the XCD's other tiles are about to re-read; with `wt` the store carries sc1
+// (write-through, the line is not kept).  Issued from inline assembly: the compiler does not count it in its vmcnt
+// bookkeeping, so its own waits for loads can only come out stricter than needed, never laxer.
+__device__ __forceinline__ void st16(void* p, u32x4_t v, int wt) {
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else *(u32x4_t*)p = v;
+}
+
 struct Epi {
   void* out;
   const void* bias;
@@ -33,6 +43,10 @@ struct Epi {
   float qk_eps;
   int qk_ln;
   int64_t rows_total;    // rows of the whole problem (a launch on the rows after a cut sees fewer)
+  int wt;                // write the epilogue's 16-byte outputs through the L2 (sc1): see st16
+  int panel_m;           // row tiles per panel of the tile walk: see tile_coords
+  int stream;            // whole tiles of the 256x256 kernel take their epilogue operand by LDS-DMA (epilogue_stream16)
+  int ntl;               // ask for the epilogue's read-once rows (saved pre-activations, residual) with the streaming policy
 };
 
 // sum of a fragment's 8 bf16 values added to s (4 x v_dot2c_f32_bf16 against ones)
@@ -66,6 +80,17 @@ __device__ __forceinline__ void asum_store(const Epi& e, const float (&rs)[NI], 
 }
 
 
+// The activation of a fused epilogue as a compile-time constant (ACTC >= 0: the caller has already switched on the
+// code, once per tile) or switched on here (ACTC < 0).  A switch inside every row step lays all five activations'
+// code out sixteen times per tile; with the switch hoisted the hot path of a tile is one activation's code.
+#define ACT_DISPATCH(ACTC, code, ACT, ...)                  \
+  if constexpr (ACTC >= 0) {                                \
+    constexpr int ACT = ACTC;                               \
+    __VA_ARGS__;                                            \
+  } else {                                                  \
+    ACT_SWITCH(code, ACT, __VA_ARGS__)                      \
+  }
+
 constexpr int EPI_ACT = VITK_EPI_ACT, EPI_GLU = VITK_EPI_GLU, EPI_DACT = VITK_EPI_DACT, EPI_DGLU = VITK_EPI_DGLU;
 constexpr int EPI_ROPE = VITK_EPI_ROPE;
 
@@ -83,11 +108,17 @@ template <class T> struct Raw4;
 template <> struct Raw4<float> {
   float4 q;
   __device__ __forceinline__ void load(const float* p) { q = *(const float4*)p; }
+  __device__ __forceinline__ void load(const float* p, int nt) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4n_t;
+    if (nt) q = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4n_t*)p));
+    else q = *(const float4*)p;
+  }
   __device__ __forceinline__ float get(int j) const { return j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w; }
 };
 template <> struct Raw4<bf16> {
   uint2 q;
   __device__ __forceinline__ void load(const bf16* p) { q = *(const uint2*)p; }
+  __device__ __forceinline__ void load(const bf16* p, int) { q = *(const uint2*)p; }
   __device__ __forceinline__ float get(int j) const {
     const uint32_t w = j < 2 ? q.x : q.y;
     return __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
@@ -107,7 +138,7 @@ struct EpiVec {
   static __device__ __forceinline__ void prefetch(const Epi& e, int64_t m, int64_t n, EpiPre<MODE, TO>& p) {
     if (MODE == VITK_EPI_RESIDUAL) {
       p.row = e.row_idx ? e.row_idx[m] : m;
-      p.r.load((const TO*)e.res + p.row * e.ldo + n);
+      p.r.load((const TO*)e.res + p.row * e.ldo + n, e.ntl);
     } else if (MODE == VITK_EPI_PATCH) {
       if (e.pos) {
         if (e.pos_f32) p.r.load((const TO*)e.pos + (m % e.tokens) * e.N + n);   // output type is float then
@@ -153,7 +184,8 @@ struct EpiVec {
 #pragma unroll
         for (int j = 0; j < 4; j++) r.v[j] = p.r.get(j) + e.alpha * v[j];
       }
-      r.store((TO*)e.out + p.row * e.ldo + n);
+      if constexpr (sizeof(TO) == 4) st16((TO*)e.out + p.row * e.ldo + n, __builtin_bit_cast(u32x4_t, *(const f32x4*)r.v), 0);
+      else r.store((TO*)e.out + p.row * e.ldo + n);
     } else if (MODE == VITK_EPI_PATCH) {
       const int64_t b = m / e.tokens, t = m % e.tokens;
       Vec4<TO> o;
@@ -324,15 +356,20 @@ constexpr bool epi_wide() {
 struct Raw8 {   // 8 bf16 as loaded
   uint4 q;
   __device__ __forceinline__ void load(const bf16* p) { q = *(const uint4*)p; }
+  // nt: a row that is read once (saved pre-activations, residual rows) is asked for with the streaming policy
+  __device__ __forceinline__ void load(const bf16* p, int nt) {
+    if (nt) q = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const u32x4_t*)p));
+    else q = *(const uint4*)p;
+  }
   __device__ __forceinline__ float get(int j) const {
     const uint32_t w = (j >> 1) == 0 ? q.x : (j >> 1) == 1 ? q.y : (j >> 1) == 2 ? q.z : q.w;
     return __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
   }
 };
-__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8], int wt = 0) {
   typedef float f32x8_t __attribute__((ext_vector_type(8)));
   const f32x8_t f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-  *(bf16x8*)p = __builtin_convertvector(f, bf16x8);   // four v_cvt_pk_bf16_f32
+  st16(p, __builtin_bit_cast(u32x4_t, __builtin_convertvector(f, bf16x8)), wt);   // four v_cvt_pk_bf16_f32
 }
 
 // Element offsets of a lane's 8 columns in one row of the output and of the saved pre-activations.  slab_finish forms them
@@ -374,14 +411,15 @@ template <int ACT> __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {   // fas
 }
 
 // GLU forward, 8 pairs: lin[8] = fc1 columns f..f+7, glu[8] = columns F+f..F+f+7 of row m (see epi_glu)
+template <int ACTC = -1>
 __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, const RowOff& ro, float (&lin)[8], float (&glu)[8],
                                          const float (&bl)[8], const float (&bg)[8]) {
   typedef bf16 TI;
   const int64_t F = e.N / 2;
 #pragma unroll
   for (int j = 0; j < 8; j++) { lin[j] += bl[j]; glu[j] += bg[j]; }
-  store8((TI*)e.aux + ro.aux, lin);
-  store8((TI*)e.aux + ro.aux + F, glu);
+  store8((TI*)e.aux + ro.aux, lin, 0);
+  store8((TI*)e.aux + ro.aux + F, glu, 0);
   float o[8];
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
@@ -397,7 +435,7 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, con
       if (e.use_extra) lin[j] = round_as<TI>(lin[j] + e.extra);
     }
   }
-  ACT_SWITCH(e.act, ACT, {
+  ACT_DISPATCH(ACTC, e.act, ACT, {
     if constexpr (act_is_sigmoid_gate<ACT>()) {
       _Pragma("unroll")
       for (int j = 0; j < 8; j += 2) {
@@ -416,10 +454,11 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, con
     for (int j = 0; j < 8; j++)
       o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + f + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
   }
-  store8((TI*)e.out + ro.out, o);
+  store8((TI*)e.out + ro.out, o, 0);
 }
 
 // DGLU, 8 columns: v = dh[m, n..n+7]; pa / pb = saved linear / gate pre-activations (see EpiVec, EPI_DGLU)
+template <int ACTC = -1>
 __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, const RowOff& ro, float (&v)[8], const Raw8& pa,
                                           const Raw8& pb) {
   typedef bf16 TI;
@@ -460,7 +499,7 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, co
       if (e.use_extra) pl[j] = round_as<TI>(pl[j] + e.extra);
     }
   }
-  ACT_SWITCH(e.act, ACT, {
+  ACT_DISPATCH(ACTC, e.act, ACT, {
     if constexpr (act_is_sigmoid_gate<ACT>()) {
       constexpr float a = ACT == VITK_ACT_SILU ? 1.f : 1.702f;
       _Pragma("unroll")
@@ -482,8 +521,8 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, co
       }
     }
   });
-  store8((TI*)e.out + ro.out, dl);
-  store8((TI*)e.out + ro.out + F, dg);
+  store8((TI*)e.out + ro.out, dl, e.wt);
+  store8((TI*)e.out + ro.out + F, dg, e.wt);
 }
 
 // RESIDUAL on a bf16 stream, 8 columns: v = linear output (bias added) of row m; res = the residual row `row`, columns
@@ -507,15 +546,16 @@ __device__ __forceinline__ void epi_res8(const Epi& e, int64_t m, int64_t row, i
 #pragma unroll
     for (int j = 0; j < 8; j++) r[j] = res.get(j) + e.alpha * v[j];
   }
-  store8((T*)e.out + row * e.ldo + n, r);
+  store8((T*)e.out + row * e.ldo + n, r, 0);
 }
 
 // ACT, 8 columns: v = fc1 output (bias added) of row m, columns n..n+7 (see EpiVec, EPI_ACT)
+template <int ACTC = -1>
 __device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, const RowOff& ro, float (&v)[8]) {
   typedef bf16 TI;
-  store8((TI*)e.aux + ro.aux, v);
+  store8((TI*)e.aux + ro.aux, v, 0);
   float o[8];
-  ACT_SWITCH(e.act, ACT, {
+  ACT_DISPATCH(ACTC, e.act, ACT, {
     _Pragma("unroll")
     for (int j = 0; j < 8; j++) o[j] = act_apply_t<ACT>(round_as<TI>(v[j]));
   });
@@ -524,10 +564,11 @@ __device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, con
     for (int j = 0; j < 8; j++)
       o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
   }
-  store8((TI*)e.out + ro.out, o);
+  store8((TI*)e.out + ro.out, o, 0);
 }
 
 // DACT, 8 columns: v = dh[m, n..n+7]; pa = saved pre-activations (see EpiVec, EPI_DACT)
+template <int ACTC = -1>
 __device__ __forceinline__ void epi_dact8(const Epi& e, int64_t m, int64_t n, const RowOff& ro, float (&v)[8], const Raw8& pa) {
   typedef bf16 TI;
 #pragma unroll
@@ -538,11 +579,11 @@ __device__ __forceinline__ void epi_dact8(const Epi& e, int64_t m, int64_t n, co
       v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
   }
   float o[8];
-  ACT_SWITCH(e.act, ACT, {
+  ACT_DISPATCH(ACTC, e.act, ACT, {
     _Pragma("unroll")
     for (int j = 0; j < 8; j++) o[j] = v[j] * act_grad_t<ACT>(pa.get(j));
   });
-  store8((TI*)e.out + ro.out, o);
+  store8((TI*)e.out + ro.out, o, e.wt);
 }
 
 template <int MODE, class TO>
@@ -647,7 +688,7 @@ __device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, 
         const int64_t mr = mbase + it * 8 + (lane >> 3);
         if (mr < M && cols.ncol < N) {
           pre.wrow[it] = e.row_idx ? e.row_idx[mr] : mr;
-          pre.wr[it].load((const bf16*)e.res + pre.wrow[it] * e.ldo + cols.ncol);
+          pre.wr[it].load((const bf16*)e.res + pre.wrow[it] * e.ldo + cols.ncol, e.ntl);
         }
       }
       return;
@@ -655,10 +696,10 @@ __device__ __forceinline__ void slab_prefetch(const Epi& e, const EpiCols<MODE, 
     const int64_t m = mbase + (lane >> 3);
     if (m < M && cols.ncol < N) {
       if (MODE == EPI_DACT) {
-        pre.wa[0].load((const bf16*)e.aux + m * e.N + cols.ncol);
+        pre.wa[0].load((const bf16*)e.aux + m * e.N + cols.ncol, e.ntl);
       } else {
-        pre.wa[0].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol);
-        pre.wb[0].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol);
+        pre.wa[0].load((const bf16*)e.aux + m * 2 * e.N + cols.ncol, e.ntl);
+        pre.wb[0].load((const bf16*)e.aux + m * 2 * e.N + e.N + cols.ncol, e.ntl);
       }
     }
     return;
@@ -680,7 +721,7 @@ __device__ __forceinline__ void slab_stage(float* stg, const f32x16& a0, const f
   }
 }
 
-template <int MODE, class TO>
+template <int MODE, class TO, int ACTC = -1>
 __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO>& cols, SlabPre<MODE, TO>& pre,
                                             const float* stg, int64_t mbase, int64_t nwave, int64_t M, int64_t N,
                                             int64_t split, float* __restrict__ partial, int lane) {
@@ -699,7 +740,7 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
       *(float4*)(lin + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
       *(float4*)glu = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv);
       *(float4*)(glu + 4) = *(const float4*)(stg + row * STG_LD + 32 + 8 * cv + 4);
-      if (m < M && nwave + 8 * cv < N) epi_glu8(e, m, ncol, ro, lin, glu, cols.wb0, cols.wb1);
+      if (m < M && nwave + 8 * cv < N) epi_glu8<ACTC>(e, m, ncol, ro, lin, glu, cols.wb0, cols.wb1);
     }
   } else if (epi_wide<MODE, TO>()) {
     const int cv = lane & 7, rr = lane >> 3;
@@ -715,17 +756,17 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
       *(float4*)v = *(const float4*)(stg + row * STG_LD + 8 * cv);
       *(float4*)(v + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
       if (MODE == EPI_DGLU && it < 3 && m + 8 < M && ncol < N) {   // the next row's pre-activations, one step ahead
-        pre.wa[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld);
-        pre.wb[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld + e.N);
+        pre.wa[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld, e.ntl);
+        pre.wb[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld + e.N, e.ntl);
       }
-      if (MODE == EPI_DACT && it < 3 && m + 8 < M && ncol < N) pre.wa[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld);
+      if (MODE == EPI_DACT && it < 3 && m + 8 < M && ncol < N) pre.wa[(it + 1) & 1].load((const bf16*)e.aux + ro.aux + 8 * aux_ld, e.ntl);
       if (m < M && ncol < N) {
-        if (MODE == EPI_DGLU) epi_dglu8(e, m, ncol, ro, v, pre.wa[it & 1], pre.wb[it & 1]);
-        else if (MODE == EPI_DACT) epi_dact8(e, m, ncol, ro, v, pre.wa[it & 1]);
+        if (MODE == EPI_DGLU) epi_dglu8<ACTC>(e, m, ncol, ro, v, pre.wa[it & 1], pre.wb[it & 1]);
+        else if (MODE == EPI_DACT) epi_dact8<ACTC>(e, m, ncol, ro, v, pre.wa[it & 1]);
         else if (MODE == EPI_ACT) {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
-          epi_act8(e, m, ncol, ro, v);
+          epi_act8<ACTC>(e, m, ncol, ro, v);
         } else if (MODE == VITK_EPI_RESIDUAL) {
 #pragma unroll
           for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
@@ -795,7 +836,7 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
               for (int j = 0; j < 8; j++) v[j] = rope_mix(v[j], cw[j], sign * u[j], sv[j], e.rope_emu);
             }
           }
-          store8((bf16*)e.out + ro.out, v);
+          store8((bf16*)e.out + ro.out, v, 0);
         }
       }
     }
@@ -819,7 +860,7 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
       float v[4];
       *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
       if (m < M && ncol < N) {
-        if (MODE == MODE_PARTIAL) *(float4*)(partial + (split * M + m) * N + ncol) = *(const float4*)v;
+        if (MODE == MODE_PARTIAL) st16(partial + (split * M + m) * N + ncol, __builtin_bit_cast(u32x4_t, *(const f32x4*)v), 0);
         else EpiVec<EMODE, TO>::apply(e, m, ncol, v, cols.bias0, cols.gam, pre.r[it]);
       }
     }
@@ -839,14 +880,15 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
 #define PANEL_M_VALUE 8
 #endif
 constexpr int PANEL_M = PANEL_M_VALUE;
-__device__ __forceinline__ void tile_coords(int64_t wg, int64_t tiles_m, int64_t tiles_n, int64_t& tm, int64_t& tn, int64_t& split) {
+__device__ __forceinline__ void tile_coords(int64_t wg, int64_t tiles_m, int64_t tiles_n, int panel_m, int64_t& tm, int64_t& tn,
+                                            int64_t& split) {
   const int64_t per_split = tiles_m * tiles_n;
   split = wg / per_split;
   const int64_t r = wg - split * per_split;
-  const int64_t per_panel = PANEL_M * tiles_n;
+  const int64_t per_panel = panel_m * tiles_n;
   const int64_t panel = r / per_panel, in_panel = r - panel * per_panel;
-  const int64_t rows_here = tiles_m - panel * PANEL_M < PANEL_M ? tiles_m - panel * PANEL_M : PANEL_M;
-  tm = panel * PANEL_M + in_panel % rows_here;
+  const int64_t rows_here = tiles_m - panel * panel_m < panel_m ? tiles_m - panel * panel_m : panel_m;
+  tm = panel * panel_m + in_panel % rows_here;
   tn = in_panel / rows_here;
 }
 
@@ -944,6 +986,121 @@ __device__ __forceinline__ void dma_barrier(bool drain_reads) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Epilogue operand stream (256x256 kernel, whole tiles).  The epilogues that read a memory operand per output element
+// (RESIDUAL: the residual row; DACT / DGLU: the saved pre-activations) are bound by how many bytes a CU keeps in flight:
+// with the rows requested into registers, one or a few steps ahead, a step waits out most of a memory latency, and
+// more steps ahead do not fit beside 128 accumulator registers.  Here a wave requests its rows by LDS-DMA into a ring
+// of its own in the (by then idle) operand area of LDS, STREAM_B bytes = 4 to 8 steps ahead, at no register cost.  Each
+// request is one wave instruction of 64 x 16 bytes whose lane order is the order the lanes read it back in, so a lane
+// only ever reads what it asked for itself and no barrier is involved.
+// The requests are issued from inline assembly and waited for with counted s_waitcnt: vmcnt retires in issue order and
+// counts loads, stores and LDS-DMA alike, so "all but the N youngest" with N = the operations issued after the wanted
+// request (later requests and the stores of the steps in between) waits for that request alone.  That count has to be a
+// compile-time constant, which is why this path runs on whole tiles only (no predicated-off store ever drops out of the
+// count; optional extra stores only make the real count larger than N, which waits longer, never shorter).
+// ------------------------------------------------------------------------------------------------
+constexpr int STREAM_B = 8192;   // bytes of requests in flight per wave
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+// one request: 64 lanes x 16 bytes from rsrc[voff + soff] to LDS bytes [lds_addr, lds_addr + 1024) in lane order.  The
+// statement first waits for the wave's LDS reads (the slot it refills has just been read); M0 is saved around it.
+__device__ __forceinline__ void dma16_asm(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+      : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MODE, class TO>
+constexpr bool epi_streams() { return MODE == EPI_DGLU || MODE == EPI_DACT || MODE == VITK_EPI_RESIDUAL; }
+
+template <int MODE, class TO>
+struct StreamCfg {
+  static constexpr bool WIDE = epi_wide<MODE, TO>();
+  static constexpr int NI = MODE == EPI_DGLU ? 2 : 1;   // requests per step (DGLU: linear and gate pre-activations)
+  static constexpr int NS = MODE == EPI_DGLU ? 2 : 1;   // stores per step that are always issued
+  static constexpr int ROWS = WIDE ? 8 : 4;             // rows of the wave's 64-column strip per step
+  static constexpr int STEPS = 128 / ROWS;              // steps per wave tile (128 rows)
+  static constexpr int PER_SLAB = 32 / ROWS;
+  static constexpr int SLOT = NI * 1024;
+  static constexpr int D = STREAM_B / SLOT;             // requests ahead
+};
+// vector-memory operations a wave has issued after the request of step j at the moment it starts step j.  Order of
+// issue: requests 0 .. D-1, then per step i: [request i + D, if there is one], [the step's stores].
+template <class C>
+constexpr int stream_younger(int j) {
+  int n = 0;
+  if (j < C::D) {
+    n += (C::D - 1 - j) * C::NI;
+    for (int i = 0; i < j; i++) n += (i + C::D < C::STEPS ? C::NI : 0) + C::NS;
+  } else {
+    n += C::NS;   // the stores of step j - D follow its request for step j
+    for (int i = j - C::D + 1; i < j; i++) n += (i + C::D < C::STEPS ? C::NI : 0) + C::NS;
+  }
+  return n;
+}
+
+template <int MODE, class TO, int J, int ACTC>
+__device__ __forceinline__ void stream_step(const Epi& e, const EpiCols<MODE, TO>& cols, const float* stg, const char* slots,
+                                            __amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off, uint32_t step_b, uint32_t lds0,
+                                            int64_t mrow0, int lane) {
+  typedef StreamCfg<MODE, TO> C;
+  constexpr int it = J % C::PER_SLAB;
+  const int cv = C::WIDE ? lane & 7 : lane & 15, rr = C::WIDE ? lane >> 3 : lane >> 4;
+  const int row = it * C::ROWS + rr;               // row inside the staged slab
+  const int64_t m = mrow0 + J * C::ROWS + rr;      // row of the problem
+  const int64_t ncol = cols.ncol;
+  wait_vmcnt<stream_younger<C>(J)>();
+  const char* slot = slots + (J % C::D) * C::SLOT + lane * 16;
+  const uint4 q0 = *(const uint4*)slot;
+  uint4 q1 = q0;
+  if (MODE == EPI_DGLU) q1 = *(const uint4*)(slot + 1024);
+  if (J + C::D < C::STEPS) {   // refill the slot just read (the statement waits for the reads above first)
+    const uint32_t soff = (uint32_t)(J + C::D) * step_b;
+    dma16_asm(rsrc, lane_off, soff, lds0 + (J % C::D) * C::SLOT);
+    if (MODE == EPI_DGLU) dma16_asm(rsrc, lane_off, soff + (uint32_t)e.N * 2u, lds0 + (J % C::D) * C::SLOT + 1024);
+  }
+  if constexpr (C::WIDE) {
+    float v[8];
+    *(float4*)v = *(const float4*)(stg + row * STG_LD + 8 * cv);
+    *(float4*)(v + 4) = *(const float4*)(stg + row * STG_LD + 8 * cv + 4);
+    const int64_t aux_ld = MODE == EPI_DGLU ? 2 * e.N : e.N;
+    const RowOff ro = {m * e.ldo + ncol, m * aux_ld + ncol};
+    Raw8 pa, pb;
+    pa.q = q0;
+    pb.q = q1;
+    if (MODE == EPI_DGLU) epi_dglu8<ACTC>(e, m, ncol, ro, v, pa, pb);
+    else if (MODE == EPI_DACT) epi_dact8<ACTC>(e, m, ncol, ro, v, pa);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] += cols.wb0[j];
+      epi_res8(e, m, m, ncol, v, cols.wb1, pa);
+    }
+  } else {   // RESIDUAL on an fp32 stream: 4 columns per lane
+    float v[4];
+    *(float4*)v = *(const float4*)(stg + row * STG_LD + 4 * cv);
+    EpiPre<VITK_EPI_RESIDUAL, TO> pre;
+    pre.row = m;
+    if constexpr (sizeof(TO) == 4) pre.r.q = __builtin_bit_cast(float4, q0);
+    EpiVec<VITK_EPI_RESIDUAL, TO>::apply(e, m, ncol, v, cols.bias0, cols.gam, pre);
+  }
+}
+
+template <int MODE, class TO, int J0, int J1>
+struct StreamSteps {
+  template <class F>
+  static __device__ __forceinline__ void run(F&& f) {
+    if constexpr (J0 < J1) {
+      f(std::integral_constant<int, J0>{});
+      StreamSteps<MODE, TO, J0 + 1, J1>::run(f);
+    }
+  }
+};
+
 // 32-row x 64-column slab (row tiles 2s, 2s+1 of a wave's 8 x 4 grid of 16x16 accumulators) -> the wave's LDS slab.
 // Accumulator register r of lane l is row 4*(l>>4) + r, column l&15 of its tile.
 __device__ __forceinline__ void slab_stage16(float* stg, const f32x4_t (&acc)[8][4], int s, int lane) {
@@ -954,4 +1111,30 @@ __device__ __forceinline__ void slab_stage16(float* stg, const f32x4_t (&acc)[8]
 #pragma unroll
       for (int r = 0; r < 4; r++)
         stg[(16 * h + 4 * (lane >> 4) + r) * STG_LD + 16 * j + (lane & 15)] = acc[2 * s + h][j][r];
+}
+
+// the whole epilogue of one wave tile (128 rows x 64 columns, 16x16 accumulators) on the operand stream
+template <int MODE, class TO, int ACTC>
+__device__ __forceinline__ void epilogue_stream16(const Epi& e, const EpiCols<MODE, TO>& cols, float* stg, char* slots,
+                                                  const f32x4_t (&acc)[8][4], int64_t mrow0, int lane) {
+  typedef StreamCfg<MODE, TO> C;
+  const int cv = C::WIDE ? lane & 7 : lane & 15, rr = C::WIDE ? lane >> 3 : lane >> 4;
+  const char* src = MODE == VITK_EPI_RESIDUAL ? (const char*)e.res : (const char*)e.aux;
+  const int64_t ld = MODE == VITK_EPI_RESIDUAL ? e.ldo : (MODE == EPI_DGLU ? 2 * e.N : e.N);
+  constexpr int esz = MODE == VITK_EPI_RESIDUAL ? (int)sizeof(TO) : 2;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(src + mrow0 * ld * esz), 0, clip32(128 * ld * esz), 0x00020000);
+  const uint32_t lane_off = (uint32_t)((rr * ld + cols.ncol) * esz);
+  const uint32_t step_b = (uint32_t)(C::ROWS * ld * esz);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_t*)slots;
+#pragma unroll
+  for (int j = 0; j < C::D; j++) {
+    dma16_asm(rsrc, lane_off, (uint32_t)j * step_b, lds0 + j * C::SLOT);
+    if (MODE == EPI_DGLU) dma16_asm(rsrc, lane_off, (uint32_t)j * step_b + (uint32_t)e.N * 2u, lds0 + j * C::SLOT + 1024);
+  }
+  StreamSteps<MODE, TO, 0, C::STEPS>::run([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    if constexpr (J % C::PER_SLAB == 0) slab_stage16(stg, acc, J / C::PER_SLAB, lane);
+    stream_step<MODE, TO, J, ACTC>(e, cols, stg, slots, rsrc, lane_off, step_b, lds0, mrow0, lane);
+  });
 }

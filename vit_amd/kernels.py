@@ -34,6 +34,12 @@ def set_dynamic_tiles(on: bool) -> bool:
     return old
 
 
+# Tuning knobs of the MFMA GEMM (VitkGemm.store_policy / panel_m): 0 = the library's choice.  Experiments set them per
+# process through the environment or per call through gemm()'s arguments.
+_STORE_POLICY = int(os.environ.get("VITK_STORE_POLICY", "0"))
+_PANEL_M = int(os.environ.get("VITK_PANEL_M", "0"))
+
+
 def _c(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -112,7 +118,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
          tokens: int = 0, seq: int = 0, prefix: int = 0, ldo: Optional[int] = None, algo: Optional[int] = None,
          tag: str = "", act: int = 0, limit: Optional[float] = None, extra: Optional[float] = None,
          a_colsum: Optional[Tensor] = None, rope: Optional[Tensor] = None, rope_width: int = 0,
-         rope_emulate_bf16: bool = False, qk_norm: Optional[dict] = None) -> Tensor:
+         rope_emulate_bf16: bool = False, qk_norm: Optional[dict] = None, store_policy: Optional[int] = None,
+         panel_m: Optional[int] = None) -> Tensor:
     """``a_colsum`` ([M], dtype of out; trans_a products only) receives sum_k A[k, m] from the same pass.
     ``rope`` (EPI_ROPE): fp32 table [2, seq - prefix, 64]; sections of ``rope_width`` columns, the first two rotated."""
     lib = L.load()
@@ -146,6 +153,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, 
     g.epilogue = epilogue
     g.algo = _ALGO if algo is None else algo
     g.dynamic_tiles = int(_DYNAMIC_TILES)
+    g.store_policy = _STORE_POLICY if store_policy is None else store_policy
+    g.panel_m = _PANEL_M if panel_m is None else panel_m
     g.pos_f32 = int(pos_f32)
     if rope is not None:
         L.require_gpu(rope)

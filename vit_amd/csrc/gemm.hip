@@ -166,13 +166,12 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_k(const bf16* __restrict__ A
   char* sB = smem + TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  int64_t tm, tn, split;
-  tile_coords(wg, tiles_m, tiles_n, e.panel_m, tm, tn, split);
-  const int64_t m0 = tm * BM, n0 = tn * BN;
+  uint32_t tm, tn, split;   // 32-bit tile arithmetic: see gemm_mfma256d_k
+  tile_coords32(xcd_remap32(blockIdx.x, gridDim.x), (uint32_t)tiles_m, (uint32_t)tiles_n, (uint32_t)e.panel_m, tm, tn, split);
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
   float rs[2] = {0.f, 0.f};
-  const int64_t kbeg = split * klen;
+  const int64_t kbeg = (int64_t)split * klen;
   const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
 
   f32x16 acc[2][2];
@@ -266,10 +265,9 @@ __global__ __launch_bounds__(512) void gemm_mfma256_k(const bf16* __restrict__ A
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;            // waves w and w+4 share a SIMD; grp 1 runs one interval behind grp 0
   const int wm = grp, wn = wid & 3;    // wave tile: rows [wm*128, +128), columns [wn*64, +64)
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  int64_t tm, tn, split;
-  tile_coords(wg, tiles_m, tiles_n, e.panel_m, tm, tn, split);
-  const int64_t m0 = tm * BM2, n0 = tn * BN2;
+  uint32_t tm, tn, split;
+  tile_coords32(xcd_remap32(blockIdx.x, gridDim.x), (uint32_t)tiles_m, (uint32_t)tiles_n, (uint32_t)e.panel_m, tm, tn, split);
+  const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
   const bool asum_on = TA && e.asum && tn == 0 && wn == 0;   // wave-uniform
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t kbeg = split * klen;
@@ -432,7 +430,8 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   // the operand ring; the epilogue lays its staging slabs (8 x 8704 B) and, behind them, the operand stream's rings
   // (8 x STREAM_B) over it
   constexpr int STREAM_BASE = 8 * 32 * STG_LD * 4;
-  __shared__ __attribute__((aligned(1024))) char smem[(STREAM_BASE + 8 * STREAM_B > 4 * SLOT_B) ? STREAM_BASE + 8 * STREAM_B : 4 * SLOT_B];
+  __shared__ __attribute__((aligned(1024))) char smem[STREAM_BASE + 8 * STREAM_B];
+  static_assert(STREAM_BASE + 8 * STREAM_B >= 4 * SLOT_B, "the epilogue's areas cover the operand ring");
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;
   STAMP_DECL
@@ -443,19 +442,21 @@ __global__ __launch_bounds__(512) void gemm_mfma256d_k(const bf16* __restrict__ 
   // available at all because another kernel (a collective on a side stream) holds it, takes fewer tiles instead of
   // making the whole launch wait for its fixed share.  The draw for the next tile is issued before the current one
   // starts and consumed after its epilogue.
-  const int64_t total_tiles = tiles_m * tiles_n * ((K + klen - 1) / klen);
-  const int xcd = blockIdx.x & 7;
-  const int64_t xcd_tiles = (total_tiles >> 3) + (xcd < (total_tiles & 7) ? 1 : 0);
-  const int64_t xcd_blocks = ((int64_t)gridDim.x - xcd + 7) >> 3;
+  // tile indices are 32-bit (the host checks the tile count): a 64-bit division is ~100 scalar instructions, and the
+  // five of them that place a tile used to be a tenth of a short-K tile's time
+  const uint32_t total_tiles = (uint32_t)tiles_m * (uint32_t)tiles_n * (uint32_t)((K + klen - 1) / klen);
+  const uint32_t xcd = blockIdx.x & 7;
+  const uint32_t xcd_tiles = (total_tiles >> 3) + (xcd < (total_tiles & 7) ? 1 : 0);
+  const uint32_t xcd_blocks = (gridDim.x - xcd + 7) >> 3;
   const bool dynamic = ctr != nullptr;   // null: fixed shares, block b of an XCD takes that XCD's tiles b, b + blocks, ...
   __shared__ unsigned int s_next;
-  for (int64_t jt = blockIdx.x >> 3; jt < xcd_tiles;) {
+  for (uint32_t jt = blockIdx.x >> 3; jt < xcd_tiles;) {
   unsigned int drawn = 0;
   if (dynamic && tid == 0) drawn = __hip_atomic_fetch_add(&ctr[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int64_t tm, tn, split;
-  tile_coords(xcd_remap(xcd + 8 * jt, total_tiles), tiles_m, tiles_n, e.panel_m, tm, tn, split);
-  const int64_t m0 = tm * BM2, n0 = tn * BN2;
-  const int64_t kbeg = split * klen;
+  uint32_t tm, tn, split;
+  tile_coords32(xcd_remap32(xcd + 8 * jt, total_tiles), (uint32_t)tiles_m, (uint32_t)tiles_n, (uint32_t)e.panel_m, tm, tn, split);
+  const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+  const int64_t kbeg = (int64_t)split * klen;
   const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
   const int32_t klen_here = (int32_t)(kend - kbeg);
   const int nk = (klen_here + BK - 1) / BK;
@@ -670,6 +671,8 @@ static bool mfma_ok(const VitkGemm* g) {
   if (g->trans_a && g->M % 8) return false;
   if (!g->trans_b && g->K % 8) return false;
   if (g->trans_b && g->N % 8) return false;
+  // the kernels place tiles with 32-bit arithmetic: at most 2^24 tiles of 128 x 128 (times up to 64 K-splits)
+  if (ceil_div(g->M, 128) * ceil_div(g->N, 128) >= (1ll << 24)) return false;
   return g->M > 0 && g->N > 0 && g->K > 0;
 }
 

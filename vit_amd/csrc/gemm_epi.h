@@ -4,6 +4,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
 // A 16-byte store of write-once output.  A plain store leaves its line in the XCD's 4 MiB L2, where a tile's 128-512 KiB of
 // output push out the operand panels that the XCD's other tiles are about to re-read; with `wt` the store carries sc1
 // (write-through, the line is not kept).  Issued from inline assembly: the compiler does not count it in its vmcnt
@@ -867,12 +868,6 @@ __device__ __forceinline__ void slab_finish(const Epi& e, const EpiCols<MODE, TO
   }
 }
 
-// blocks that share an XCD (bid % 8) get consecutive tile ids, so one L2 sees neighbouring tiles
-__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
-  const int64_t xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
 // Tile order inside one split: panels of PANEL_M row tiles, walked column tile by column tile.  The blocks of an XCD
 // run consecutive tile ids, so at any time they share a few B column tiles and one panel of A rows, and each B tile is
 // fetched into that XCD's L2 once per panel instead of once per row tile.
@@ -880,16 +875,23 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
 #define PANEL_M_VALUE 8
 #endif
 constexpr int PANEL_M = PANEL_M_VALUE;
-__device__ __forceinline__ void tile_coords(int64_t wg, int64_t tiles_m, int64_t tiles_n, int panel_m, int64_t& tm, int64_t& tn,
-                                            int64_t& split) {
-  const int64_t per_split = tiles_m * tiles_n;
+// Tile indices are 32-bit: a 64-bit division is ~100 scalar instructions, and the handful of them that places a tile cost
+// a tenth of a short-K tile's time when they were 64-bit.  Blocks that share an XCD (bid % 8) get consecutive tile ids, so
+// one L2 sees neighbouring tiles.
+__device__ __forceinline__ uint32_t xcd_remap32(uint32_t bid, uint32_t nwg) {
+  const uint32_t xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+__device__ __forceinline__ void tile_coords32(uint32_t wg, uint32_t tiles_m, uint32_t tiles_n, uint32_t panel_m, uint32_t& tm,
+                                              uint32_t& tn, uint32_t& split) {
+  const uint32_t per_split = tiles_m * tiles_n;
   split = wg / per_split;
-  const int64_t r = wg - split * per_split;
-  const int64_t per_panel = panel_m * tiles_n;
-  const int64_t panel = r / per_panel, in_panel = r - panel * per_panel;
-  const int64_t rows_here = tiles_m - panel * panel_m < panel_m ? tiles_m - panel * panel_m : panel_m;
-  tm = panel * panel_m + in_panel % rows_here;
+  const uint32_t r = wg - split * per_split;
+  const uint32_t per_panel = panel_m * tiles_n;
+  const uint32_t panel = r / per_panel, in_panel = r - panel * per_panel;
+  const uint32_t left = tiles_m - panel * panel_m, rows_here = left < panel_m ? left : panel_m;
   tn = in_panel / rows_here;
+  tm = panel * panel_m + (in_panel - tn * rows_here);
 }
 
 constexpr int HS_B = 16384;        // one operand's half-stage
@@ -1001,7 +1003,6 @@ __device__ __forceinline__ void dma_barrier(bool drain_reads) {
 // count; optional extra stores only make the real count larger than N, which waits longer, never shorter).
 // ------------------------------------------------------------------------------------------------
 constexpr int STREAM_B = 8192;   // bytes of requests in flight per wave
-typedef __attribute__((address_space(3))) char lds_char_t;
 
 // one request: 64 lanes x 16 bytes from rsrc[voff + soff] to LDS bytes [lds_addr, lds_addr + 1024) in lane order.  The
 // statement first waits for the wave's LDS reads (the slot it refills has just been read); M0 is saved around it.
@@ -1118,7 +1119,7 @@ template <int MODE, class TO, int ACTC>
 __device__ __forceinline__ void epilogue_stream16(const Epi& e, const EpiCols<MODE, TO>& cols, float* stg, char* slots,
                                                   const f32x4_t (&acc)[8][4], int64_t mrow0, int lane) {
   typedef StreamCfg<MODE, TO> C;
-  const int cv = C::WIDE ? lane & 7 : lane & 15, rr = C::WIDE ? lane >> 3 : lane >> 4;
+  const int rr = C::WIDE ? lane >> 3 : lane >> 4;
   const char* src = MODE == VITK_EPI_RESIDUAL ? (const char*)e.res : (const char*)e.aux;
   const int64_t ld = MODE == VITK_EPI_RESIDUAL ? e.ldo : (MODE == EPI_DGLU ? 2 * e.N : e.N);
   constexpr int esz = MODE == VITK_EPI_RESIDUAL ? (int)sizeof(TO) : 2;

@@ -411,6 +411,36 @@ template <int ACT> __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {   // fas
   return r;
 }
 
+// sigmoid2 on four pairs, stage by stage (all scalings, then all exponentials, the increments, all reciprocals).  Written
+// pair by pair the compiler emits each pair's chain on its own, every instruction waiting for the one before it (an
+// exponential's result is not ready for several cycles); the register fences between the stages keep four independent
+// chains in flight.  Same operations per element, so the same values.
+__device__ __forceinline__ void stage_fence(f32x2 (&t)[4]) {
+  asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+}
+template <int ACT> __device__ __forceinline__ void sigmoid8(const float (&x)[8], f32x2 (&r)[4]) {
+  constexpr float a = ACT == VITK_ACT_SILU ? 1.f : 1.702f;
+  f32x2 t[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) t[p] = f32x2{x[2 * p], x[2 * p + 1]} * (-1.44269504088896340736f * a);
+  stage_fence(t);
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    t[p].x = __builtin_amdgcn_exp2f(t[p].x);
+    t[p].y = __builtin_amdgcn_exp2f(t[p].y);
+  }
+  stage_fence(t);
+#pragma unroll
+  for (int p = 0; p < 4; p++) t[p] = 1.f + t[p];
+  stage_fence(t);
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    r[p].x = __builtin_amdgcn_rcpf(t[p].x);
+    r[p].y = __builtin_amdgcn_rcpf(t[p].y);
+  }
+  stage_fence(r);
+}
+
 // GLU forward, 8 pairs: lin[8] = fc1 columns f..f+7, glu[8] = columns F+f..F+f+7 of row m (see epi_glu)
 template <int ACTC = -1>
 __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, const RowOff& ro, float (&lin)[8], float (&glu)[8],
@@ -438,10 +468,12 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, con
   }
   ACT_DISPATCH(ACTC, e.act, ACT, {
     if constexpr (act_is_sigmoid_gate<ACT>()) {
+      f32x2 sg[4];
+      sigmoid8<ACT>(glu, sg);
       _Pragma("unroll")
       for (int j = 0; j < 8; j += 2) {
         const f32x2 g = {glu[j], glu[j + 1]}, l = {lin[j], lin[j + 1]};
-        const f32x2 r = round_bf16x2(g * sigmoid2<ACT>(g)) * l;
+        const f32x2 r = round_bf16x2(g * sg[j >> 1]) * l;
         o[j] = r.x;
         o[j + 1] = r.y;
       }
@@ -503,11 +535,13 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, co
   ACT_DISPATCH(ACTC, e.act, ACT, {
     if constexpr (act_is_sigmoid_gate<ACT>()) {
       constexpr float a = ACT == VITK_ACT_SILU ? 1.f : 1.702f;
+      f32x2 sg4[4];
+      sigmoid8<ACT>(pg, sg4);
       _Pragma("unroll")
       for (int j = 0; j < 8; j += 2) {
         const f32x2 g = {pg[j], pg[j + 1]}, l = {pl[j], pl[j + 1]};
         f32x2 vl = {dl[j], dl[j + 1]}, vg = {dg[j], dg[j + 1]};
-        const f32x2 sg = sigmoid2<ACT>(g);
+        const f32x2 sg = sg4[j >> 1];
         vl *= round_bf16x2(g * sg);                              // act_apply_t
         const f32x2 one_minus = sg * -1.f + 1.f;                 // 1 - s as one packed fma (exact: a single rounding)
         vg *= l * (sg * (1.f + (a * g) * one_minus));            // act_grad_t

@@ -821,6 +821,15 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
 
 // ---- backward: dK, dV ---------------------------------------------------------------------------
 // Query rows at or beyond S carry -lse = -inf, so their probability (and with it dS) is exactly 0.
+// Without dropout the per-query constants ride in as the INITIAL accumulators of the two score products: the stationary
+// K fragments are pre-multiplied by scale * log2(e), so S' = (c K) Q^T - lse * log2(e) leaves its MFMA chain ready for
+// exp2, and dP' = dO V^T - delta leaves its chain ready to be multiplied by P.  That takes the fused multiply-add and the
+// subtraction out of every element's vector work (the constants are accumulator rows here, so they cost no registers:
+// the four LDS reads that used to feed the arithmetic feed the chains instead).  sL holds -lse * log2(e) [64] and,
+// without dropout, -delta [64] (otherwise +delta, and the arithmetic stays per element).  Head sizes above 64 keep the
+// per-element form as well: their instances are at the register limit, and two more live accumulator tiles at the head
+// of the chains spill (head_dim 80, S = 256: 0.19 against 0.165 ms).
+template <int DHP, bool DROP> constexpr bool dkdv_init_consts() { return !DROP && DHP <= 64; }
 template <int DHP, int HALVES, bool DROP, int QS, int QW = 1>
 __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const char* sG, const float* sL,
                                           const bf16x8 (&kf)[DHP / 16], const bf16x8 (&vf)[DHP / 16],
@@ -828,33 +837,54 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
                                           int64_t sbase, int krow, int lane) {
   const f32x16 zero = ZERO16;
   const int rowoff = 4 * (lane >> 5);
+  constexpr bool INIT = dkdv_init_consts<DHP, DROP>();
 #pragma unroll
   for (int st = 0; st < HALVES; st++) {
     // sacc[r] = S[q = q0 + st*32 + row(r)][key = lane&31], pacc likewise for dP
-    f32x16 sacc = MFMA(frag_rows<QS, QW>(sQ, st * 32, 0, lane), kf[0], zero, 0, 0, 0);
-    f32x16 pacc = MFMA(frag_rows<QS, QW>(sG, st * 32, 0, lane), vf[0], zero, 0, 0, 0);
+    f32x16 sinit = zero, pinit = zero;
+    if (INIT) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int ql = st * 32 + 8 * g + rowoff;
+        const f32x4 l4 = *(const f32x4*)(sL + ql);
+        const f32x4 d4 = *(const f32x4*)(sL + 64 + ql);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { sinit[4 * g + j] = l4[j]; pinit[4 * g + j] = d4[j]; }
+      }
+    }
+    f32x16 sacc = MFMA(frag_rows<QS, QW>(sQ, st * 32, 0, lane), kf[0], sinit, 0, 0, 0);
+    f32x16 pacc = MFMA(frag_rows<QS, QW>(sG, st * 32, 0, lane), vf[0], pinit, 0, 0, 0);
 #pragma unroll
     for (int ks = 1; ks < DHP / 16; ks++) {
       sacc = MFMA(frag_rows<QS, QW>(sQ, st * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
       pacc = MFMA(frag_rows<QS, QW>(sG, st * 32, ks, lane), vf[ks], pacc, 0, 0, 0);
     }
+    if (INIT) {
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int ql = st * 32 + 8 * g + rowoff;
-      const f32x4 l4 = *(const f32x4*)(sL + ql);
-      const f32x4 d4 = *(const f32x4*)(sL + 64 + ql);
+      for (int r = 0; r < 16; r++) {
+        const float pr = fast_exp2(sacc[r]);
+        sacc[r] = pr;                  // P for dV
+        pacc[r] = pr * pacc[r];        // dS for dK
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int r = 4 * g + j;
-        const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
-        float pd = pr, dp = pacc[r];
-        if (DROP) {
-          const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.Sk + (uint64_t)krow) >= p.thr;
-          pd = keep ? pr * p.keep_scale : 0.f;
-          dp = keep ? dp * p.keep_scale : 0.f;
+      for (int g = 0; g < 4; g++) {
+        const int ql = st * 32 + 8 * g + rowoff;
+        const f32x4 l4 = *(const f32x4*)(sL + ql);
+        const f32x4 d4 = *(const f32x4*)(sL + 64 + ql);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int r = 4 * g + j;
+          const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
+          float pd = pr, dp = pacc[r];
+          if (DROP) {
+            const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.Sk + (uint64_t)krow) >= p.thr;
+            pd = keep ? pr * p.keep_scale : 0.f;
+            dp = keep ? dp * p.keep_scale : 0.f;
+          }
+          sacc[r] = pd;                  // P (dropped) for dV
+          pacc[r] = pr * (dp - d4[j]);   // dS for dK
         }
-        sacc[r] = pd;                  // P (dropped) for dV
-        pacc[r] = pr * (dp - d4[j]);   // dS for dK
       }
     }
 #pragma unroll
@@ -907,7 +937,7 @@ __global__ __launch_bounds__(NW * 64, (((DHP <= 64 || (DHP <= 96 && NW == 4)) &&
     const int qq = q0 + (tid & 63);
     const uint32_t off = wid < 2 ? (uint32_t)qq * 4u : OOB_OFF;   // wid is wave-uniform: scalar descriptor select
     const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wid == 0 ? lrs : drs, off, 0, 0));
-    rl = wid == 0 ? (qq < S ? -v * LOG2E : -INFINITY) : v;
+    rl = wid == 0 ? (qq < S ? -v * LOG2E : -INFINITY) : (dkdv_init_consts<DHP, DROP>() ? -v : v);   // see dkdv_tile
   };
   bf16x8 kf[DHP / 16], vf[DHP / 16];   // stationary operands first (see attn_fwd_k)
   load_stationary<DHP>(kf, kp, p.k_ss, krow, Sk, Dh, lane);
@@ -921,6 +951,12 @@ __global__ __launch_bounds__(NW * 64, (((DHP <= 64 || (DHP <= 96 && NW == 4)) &&
     load_row_consts(rlB, 64);
   }
   const float c = p.scale * LOG2E;
+  if (dkdv_init_consts<DHP, DROP>()) {   // the score product then comes out in exp2 units (dkdv_tile)
+#pragma unroll
+    for (int ks = 0; ks < DHP / 16; ks++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) kf[ks][j] = (bf16)((float)kf[ks][j] * c);
+  }
   const f32x16 zero = ZERO16;
   f32x16 dkacc[DHP / 32], dvacc[DHP / 32];
 #pragma unroll

@@ -286,7 +286,7 @@ def test_cross_attention_forward_backward(Sq, Sk, Dh, mode):
 
 
 def test_cross_attention_dropout_masks_agree_between_kernel_families():
-    """Both families draw the keep decision of (query, key) from the same counter, query * Sk + key, so with dropout on they
+    """Both families draw the keep decision of (query, key) from the same counter, query * (Sk rounded up to even) + key, so with dropout on they
     agree with each other to rounding, forward and backward."""
     B, H, Sq, Sk, Dh, p = 2, 2, 70, 150, 64, 0.3
     D = H * Dh

@@ -34,6 +34,9 @@ struct AttnP {
 };
 
 #define LOG2E 1.4426950408889634f
+// Dropout counter of probability (query row, key): row * drop_ld(Sk) + key, with the row stride rounded up to even so
+// that keys 2i and 2i + 1 of every row share one hash (rng_pair)
+__device__ __forceinline__ uint64_t drop_ld(int64_t Sk) { return (uint64_t)((Sk + 1) & ~(int64_t)1); }
 
 // delta[b,h,s] = sum_d dO * O   (one wave per row)
 template <class T>
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_k(AttnP p) {
     o[i] = 0.f;
   }
   float m = -INFINITY, l = 0.f;
-  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.Sk;
+  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * drop_ld(p.Sk);
   for (int64_t k0 = 0; k0 < p.Sk; k0 += PT) {
     __syncthreads();
     pload_tile<T>(Ks, kp, p.k_ss, k0, p.Sk, Dh, tid);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_dq_simple_k(AttnP p) {
   }
   const int64_t srow = (b * p.H + h) * p.S + qrow;
   const float lse = qv ? p.lse[srow] : 0.f, delta = qv ? p.delta[srow] : 0.f;
-  const uint64_t rbase = (uint64_t)srow * p.Sk;
+  const uint64_t rbase = (uint64_t)srow * drop_ld(p.Sk);
   for (int64_t k0 = 0; k0 < p.Sk; k0 += PT) {
     __syncthreads();
     pload_tile<T>(Ks, kp, p.k_ss, k0, p.Sk, Dh, tid);
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_simple_k(AttnP p) {
       const float pr = expf(s - Ls[qq]);
       float pd = pr;
       if (p.thr) {
-        const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + qq) * p.Sk + (uint64_t)krow) >= p.thr;
+        const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + qq) * drop_ld(p.Sk) + (uint64_t)krow) >= p.thr;
         pd = keep ? pr * p.keep_scale : 0.f;
         dp = keep ? dp * p.keep_scale : 0.f;
       }
@@ -591,12 +594,16 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
     for (int s2 = 0; s2 < 2; s2++) {
       bf16x8 pf = acc_to_frag(sacc[st], s2);
       lacc = MFMA(ones, pf, lacc, 0, 0, 0);
-      if (DROP) {
+      if (DROP) {   // registers 8 s2 + 0..3 and + 4..7 are two runs of four consecutive keys, each from a multiple of 4
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int key = k0 + st * 32 + acc_row(8 * s2 + j) + rowoff;
-          if (rng_u32(p.seed, rbase + (uint64_t)key) < p.thr) sacc[st][8 * s2 + j] = 0.f;
-          else sacc[st][8 * s2 + j] *= p.keep_scale;
+        for (int g = 0; g < 2; g++) {
+          uint32_t dr[4];
+          rng_run<4>(p.seed, rbase + (uint64_t)(k0 + st * 32 + acc_row(8 * s2 + 4 * g) + rowoff), dr);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int r = 8 * s2 + 4 * g + j;
+            sacc[st][r] = dr[j] < p.thr ? 0.f : sacc[st][r] * p.keep_scale;
+          }
         }
         pf = acc_to_frag(sacc[st], s2);
       }
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   for (int dt = 0; dt < DHP / 32; dt++) oacc[dt] = zero;
   float m = -INFINITY;
   const float c = p.scale * LOG2E;
-  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * p.Sk;
+  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * drop_ld(p.Sk);
   stage_store<DHP, NT, NCH, KS, false>(rkA, smem, tid);
   stage_store<DHP, NT, NCH, VS, false>(rvA, smem + 64 * KS, tid);
   __syncthreads();
@@ -715,13 +722,19 @@ __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const ch
     }
     // dS^T[key][q] = P (dP - delta); keys beyond S contribute nothing
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int key = k0 + st * 32 + acc_row(r) + rowoff;
-      float pr = fast_exp2(fmaf(sacc[r], c, nlse2));
-      if (PARTIAL && st == HALVES - 1) pr = key < S ? pr : 0.f;
-      float dp = pacc[r];
-      if (DROP) dp = rng_u32(p.seed, rbase + (uint64_t)key) >= p.thr ? dp * p.keep_scale : 0.f;
-      sacc[r] = pr * (dp - delta);
+    for (int g = 0; g < 4; g++) {   // registers 4 g .. 4 g + 3: four consecutive keys from a multiple of 4
+      uint32_t dr[4] = {0u, 0u, 0u, 0u};
+      if (DROP) rng_run<4>(p.seed, rbase + (uint64_t)(k0 + st * 32 + acc_row(4 * g) + rowoff), dr);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = 4 * g + j;
+        const int key = k0 + st * 32 + acc_row(r) + rowoff;
+        float pr = fast_exp2(fmaf(sacc[r], c, nlse2));
+        if (PARTIAL && st == HALVES - 1) pr = key < S ? pr : 0.f;
+        float dp = pacc[r];
+        if (DROP) dp = dr[j] >= p.thr ? dp * p.keep_scale : 0.f;
+        sacc[r] = pr * (dp - delta);
+      }
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
@@ -778,7 +791,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
     if (qv && lane < 32) p.delta[srow] = delta;
   }
   const float c = p.scale * LOG2E;
-  const uint64_t rbase = (uint64_t)srow * p.Sk;
+  const uint64_t rbase = (uint64_t)srow * drop_ld(p.Sk);
   const f32x16 zero = ZERO16;
   f32x16 dqacc[DHP / 32];
 #pragma unroll
@@ -878,7 +891,7 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
           const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
           float pd = pr, dp = pacc[r];
           if (DROP) {
-            const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * p.Sk + (uint64_t)krow) >= p.thr;
+            const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * drop_ld(p.Sk) + (uint64_t)krow) >= p.thr;
             pd = keep ? pr * p.keep_scale : 0.f;
             dp = keep ? dp * p.keep_scale : 0.f;
           }

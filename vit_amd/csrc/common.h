@@ -108,15 +108,30 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- counter-based dropout stream --------------------------------------------------------------
-// One 32-bit draw per (seed, 64-bit element index); forward and backward regenerate the same mask.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+// The keep decision of element idx is a function of (seed, idx) only, so forward and backward regenerate the same
+// mask.  One 32-bit hash serves the two elements of a pair (idx >> 1): element 2i takes its low half, element 2i + 1 its
+// high half, each as the top 16 bits of the draw that is compared with the threshold p * 2^32 (the keep probability is
+// then exact to 2^-16).  An element costs half a hash that way, and the integer multiplies of the hash are what a
+// dropout epilogue is made of (they issue at a quarter of the vector rate).
+__device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair) {
+  const uint32_t lo = (uint32_t)pair ^ (uint32_t)seed;
+  const uint32_t hi = (uint32_t)(pair >> 32) ^ (uint32_t)(seed >> 32);
+  uint32_t x = lo * 0x9E3779B1u + hi * 0x85EBCA77u + 0x165667B1u;
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
-  uint32_t lo = (uint32_t)idx ^ (uint32_t)seed;
-  uint32_t hi = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
-  return mix32(mix32(lo) + 0x9e3779b9U * (hi + 1U) + hi);
+__device__ __forceinline__ uint32_t rng_half(uint32_t h, int odd) { return odd ? (h & 0xffff0000u) : (h << 16); }
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) { return rng_half(rng_pair(seed, idx >> 1), (int)(idx & 1)); }
+// draws of the N consecutive elements base .. base + N - 1, base EVEN and N even: N / 2 hashes
+template <int N>
+__device__ __forceinline__ void rng_run(uint64_t seed, uint64_t base, uint32_t (&r)[N]) {
+  const uint64_t pair0 = base >> 1;
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const uint32_t h = rng_pair(seed, pair0 + (uint64_t)(j >> 1));
+    r[j] = h << 16;
+    r[j + 1] = h & 0xffff0000u;
+  }
 }
 // keep with probability 1-p:  u32 >= thr, thr = p * 2^32
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {

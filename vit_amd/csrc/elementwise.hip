@@ -536,9 +536,10 @@ __global__ __launch_bounds__(256) void act_fwd_k(const T* __restrict__ p, T* __r
       for (int j = 0; j < 4; j++) o.v[j] = act_apply(act, a.v[j]);
     }
     if (thr) {
+      uint32_t dr[4];
+      rng_run<4>(seed, (uint64_t)(r * F + c), dr);   // c and the row length are multiples of 4
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        o.v[j] = rng_u32(seed, (uint64_t)(r * F + c + j)) >= thr ? round_as<T>(o.v[j]) * keep_scale : 0.f;
+      for (int j = 0; j < 4; j++) o.v[j] = dr[j] >= thr ? round_as<T>(o.v[j]) * keep_scale : 0.f;
     }
     o.store(h + r * F + c);
   }
@@ -557,8 +558,10 @@ __global__ __launch_bounds__(256) void act_bwd_k(const T* __restrict__ dh, const
     Vec4<T> g, a;
     g.load(dh + r * F + c);
     if (thr) {
+      uint32_t dr[4];
+      rng_run<4>(seed, (uint64_t)(r * F + c), dr);   // c and the row length are multiples of 4
 #pragma unroll
-      for (int j = 0; j < 4; j++) g.v[j] = rng_u32(seed, (uint64_t)(r * F + c + j)) >= thr ? g.v[j] * keep_scale : 0.f;
+      for (int j = 0; j < 4; j++) g.v[j] = dr[j] >= thr ? g.v[j] * keep_scale : 0.f;
     }
     if (GLU) {
       Vec4<T> lin, dl, dg;
@@ -864,8 +867,10 @@ __global__ __launch_bounds__(256) void scale_cast_k(const TG* __restrict__ g, in
       for (int j = 0; j < 4; j++) o.v[j] = v.v[j] * alpha;
     }
     if (thr) {
+      uint32_t dr[4];
+      rng_run<4>(seed, (uint64_t)(r * N + c), dr);   // c and the row length are multiples of 4
 #pragma unroll
-      for (int j = 0; j < 4; j++) o.v[j] = rng_u32(seed, (uint64_t)(r * N + c + j)) >= thr ? o.v[j] * keep_scale : 0.f;
+      for (int j = 0; j < 4; j++) o.v[j] = dr[j] >= thr ? o.v[j] * keep_scale : 0.f;
     }
     o.store(out + r * N + c);
   }

@@ -167,9 +167,10 @@ struct EpiVec {
 #pragma unroll
       for (int j = 0; j < 4; j++) v[j] = round_as<TI>(v[j]);
       if (e.thr) {   // one uniform branch for the vector, not one per element (a taken scalar branch costs a refetch)
+        uint32_t dr[4];
+        rng_run<4>(e.seed, (uint64_t)((m + e.m_off) * e.N + n), dr);   // n and N are multiples of 4
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
+        for (int j = 0; j < 4; j++) v[j] = dr[j] >= e.thr ? round_as<TI>(v[j] * e.keep_scale) : 0.f;
       }
       if (e.aux) {
         Vec4<TI> a;
@@ -483,9 +484,10 @@ __device__ __forceinline__ void epi_glu8(const Epi& e, int64_t m, int64_t f, con
     }
   });
   if (e.thr) {
+    uint32_t dr[8];
+    rng_run<8>(e.seed, (uint64_t)((m + e.m_off) * F + f), dr);   // f and F are multiples of 8
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + f + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
+    for (int j = 0; j < 8; j++) o[j] = dr[j] >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
   }
   store8((TI*)e.out + ro.out, o, 0);
 }
@@ -509,9 +511,10 @@ __device__ __forceinline__ void epi_dglu8(const Epi& e, int64_t m, int64_t n, co
     v[j + 1] = r.y;
   }
   if (e.thr) {   // one uniform branch for the vector, not one per element
+    uint32_t dr[8];
+    rng_run<8>(e.seed, (uint64_t)((m + e.m_off) * F + n), dr);
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * F + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+    for (int j = 0; j < 8; j++) v[j] = dr[j] >= e.thr ? v[j] * e.keep_scale : 0.f;
   }
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -568,9 +571,10 @@ __device__ __forceinline__ void epi_res8(const Epi& e, int64_t m, int64_t row, i
 #pragma unroll
   for (int j = 0; j < 8; j++) v[j] = round_as<T>(v[j]);
   if (e.thr) {
+    uint32_t dr[8];
+    rng_run<8>(e.seed, (uint64_t)((m + e.m_off) * e.N + n), dr);
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<T>(v[j] * e.keep_scale) : 0.f;
+    for (int j = 0; j < 8; j++) v[j] = dr[j] >= e.thr ? round_as<T>(v[j] * e.keep_scale) : 0.f;
   }
   if (e.aux) store8((T*)e.aux + m * e.N + n, v);
   float r[8];
@@ -595,9 +599,10 @@ __device__ __forceinline__ void epi_act8(const Epi& e, int64_t m, int64_t n, con
     for (int j = 0; j < 8; j++) o[j] = act_apply_t<ACT>(round_as<TI>(v[j]));
   });
   if (e.thr) {
+    uint32_t dr[8];
+    rng_run<8>(e.seed, (uint64_t)((m + e.m_off) * e.N + n), dr);
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      o[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
+    for (int j = 0; j < 8; j++) o[j] = dr[j] >= e.thr ? round_as<TI>(o[j]) * e.keep_scale : 0.f;
   }
   store8((TI*)e.out + ro.out, o, 0);
 }
@@ -609,9 +614,10 @@ __device__ __forceinline__ void epi_dact8(const Epi& e, int64_t m, int64_t n, co
 #pragma unroll
   for (int j = 0; j < 8; j++) v[j] = round_as<TI>(v[j]);
   if (e.thr) {
+    uint32_t dr[8];
+    rng_run<8>(e.seed, (uint64_t)((m + e.m_off) * e.N + n), dr);
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      v[j] = rng_u32(e.seed, (uint64_t)((m + e.m_off) * e.N + n + j)) >= e.thr ? v[j] * e.keep_scale : 0.f;
+    for (int j = 0; j < 8; j++) v[j] = dr[j] >= e.thr ? v[j] * e.keep_scale : 0.f;
   }
   float o[8];
   ACT_DISPATCH(ACTC, e.act, ACT, {

@@ -103,7 +103,7 @@ def fc1_kernel_name(c: dict, autocast: bool) -> str:
     return f"gemm_mfma256d_k<NT,{epi},bf16> (fc1 forward)"
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
 FC1_KERNEL_ROW = "gemm_mfma256d_k<false, false, 4, bf16>"   # its name in tools/pmc_summary.py's table
 
 
@@ -112,10 +112,11 @@ def counter_summary(workload: str, batch: int):
     this same command (tools/pmc_collect.sh, tools/pmc_summary.py): memory-side bytes per fc1 launch (FETCH_SIZE with
     the gfx950 correction + WRITE_SIZE) and the matrix-unit busy fractions.  They are not measured by this run -- a
     process cannot read the counters of its own kernels -- so the build they were taken on is reported beside them.
-    (None, None) for a workload / batch the passes were not taken on."""
+    The third value gives the normalisation kernels (HBM-bound) their memory-side rate over the 8 TB/s peak.
+    (None, None, None) for a workload / batch the passes were not taken on."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)
     if workload != "vit_b14_224_swiglu_reg16_fourier" or batch != 256 or not os.path.exists(path):
-        return None, None
+        return None, None, None
     with open(path) as f:
         summ = json.load(f)
     row = next((k for k in summ["kernels"] if k["kernel"] == FC1_KERNEL_ROW), None)
@@ -124,7 +125,14 @@ def counter_summary(workload: str, batch: int):
             "fc1_mfma_busy_frac": None if row is None else row["mfma_busy_frac"],
             "definition": summ["formulas"]["mfma_busy_frac"], "source": PMC_SUMMARY,
             "taken_on_build": summ["build"]}
-    return traffic, util
+    norm = {"peak_gbps": PEAK_HBM_GBS, "source": PMC_SUMMARY,
+            "definition": "(2 * FETCH_SIZE + WRITE_SIZE) KiB of the kernel's launches / their summed duration"}
+    for key, prefix in (("norm_fwd", "norm_fwd_k<float, bool"), ("norm_bwd", "norm_bwd_k<bool")):
+        r = next((k for k in summ["kernels"] if k["kernel"].startswith(prefix)), None)   # the bf16-output instances
+        if r is not None and r.get("hbm_side_gbps"):
+            norm[key] = {"kernel": r["kernel"], "ms_per_step": r["ms_per_step"], "achieved_gbps": r["hbm_side_gbps"],
+                         "frac": round(r["hbm_side_gbps"] / PEAK_HBM_GBS, 4)}
+    return traffic, util, norm
 
 
 def cpu_baseline(w: dict, seconds: float = 20.0) -> dict:
@@ -281,7 +289,7 @@ def main() -> None:
     if rank == 0:
         imgs = B * world * args.steps / elapsed
         fpi = flops_per_image(c)
-        traffic, mfma_util = counter_summary(args.workload, B)
+        traffic, mfma_util, norm_hbm = counter_summary(args.workload, B)
         rec = {
             "metric": "train images/sec ViT-B/14 224px bf16" if args.workload == "vit_b14_224_swiglu_reg16_fourier" else
                       f"{'forward' if fwd_only else 'train'} images/sec {args.workload}",
@@ -299,6 +307,7 @@ def main() -> None:
                          "traffic": traffic, "traffic_source": PMC_SUMMARY if traffic is not None else None,
                          "launch_ms": round(k_ms, 4), "launches_timed": len(pairs), "flop_per_launch": k_flop},
             "mfma_util": mfma_util,
+            "norm_hbm": norm_hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w)

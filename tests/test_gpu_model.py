@@ -410,6 +410,37 @@ def test_vit_b14_fourier_swiglu_autocast_matches_oracle(algo):
         K.set_algo(old)
 
 
+def test_bf16_gradient_copies_are_handed_from_block_to_block():
+    """fp32 residual stream under autocast: each sub-layer's norm backward writes the bf16 copy of the gradient it returns,
+    and the sub-layer before it takes that copy in place of a cast - every offer but the first block's.  A gradient hook
+    that rebuilds the tensor loses the hand-off (and nothing else): the gradients stay the same."""
+    from vit_amd import ops
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(56, 56), depth=3, hidden_size=128, ffn_hidden_size=256,
+                    num_attention_heads=2, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu",
+                    pos_enc="fourier", num_register_tokens=4, dtype=torch.float32)
+    model = cfg.instantiate(device=DEV).train()
+    x = torch.randn(4, 3, 56, 56, device=DEV)
+
+    def step(hook_block=None):
+        model.zero_grad(set_to_none=True)
+        ops.carry_stats(reset=True)
+        handle = None
+        if hook_block is not None:   # the hook returns a new tensor: the copy attached to the old one stays behind
+            handle = model.blocks[hook_block].register_full_backward_pre_hook(lambda m, g: tuple(t * 1.0 for t in g))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            model(x).dense_features.float().square().mean().backward()
+        if handle is not None:
+            handle.remove()
+        return ops.carry_stats(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    stats, grads = step()
+    assert stats == {"offered": 2 * cfg.depth, "taken": 2 * cfg.depth - 1}, stats
+    stats_h, grads_h = step(hook_block=1)
+    assert stats_h["taken"] == stats["taken"] - 1, stats_h
+    for k in grads:
+        close(grads_h[k], grads[k], 1e-5, k)
+
+
 def test_vit_l16_rope_srelu_bf16_matches_oracle():
     """BASELINE config 3 at depth 2: pure bf16 parameters, RoPE, SReLU, S = 576."""
     cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(384, 384), depth=2, hidden_size=1024,

@@ -16,6 +16,7 @@ the hook finds the gradient already in place."""
 from __future__ import annotations
 
 import contextlib
+import time
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -102,6 +103,7 @@ class BucketedGradAllReduce:
         self._handles = []
         self._sync = True
         self._next = 0   # index of the first bucket not yet issued
+        self.timeline = None   # a list while tracing: (bucket index, event on the compute stream at issue, host time)
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
@@ -156,6 +158,10 @@ class BucketedGradAllReduce:
 
     def _launch(self, b: _Bucket) -> None:
         b.issued = True
+        if self.timeline is not None and b.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()   # where the backward pass stands when this bucket's collective is queued
+            self.timeline.append((self.buckets.index(b), ev, time.perf_counter()))
         if self._reduce:
             if self._host_staged:
                 b.host = b.flat.cpu()

@@ -340,7 +340,24 @@ def _residual_gemm(inp: Tensor, w_c: Tensor, b_c: Optional[Tensor], x2: Tensor, 
 # tensor object autograd hands it.  If autograd had to build another tensor on the way (a gradient accumulated from two
 # consumers, a dtype conversion), the attribute is simply not there and the consumer casts as usual; an accumulation
 # done in place into the carrying tensor changes its version counter, which the consumer checks.
+#
+# Why the tensor object and not a table keyed by address: a freed gradient's address is reused by the caching allocator
+# for the next tensor of that size, so only the identity of the Python object proves the values are the ones the copy was
+# made from.  Why not one autograd node per block: the sub-layers are modules whose hooks must keep firing, and the
+# hand-off from one block's attention sub-layer to the previous block's MLP crosses nodes in any case.
+# A lost hand-off costs one cast kernel and no accuracy; carry_stats() counts offers and takes so that a training loop
+# (or a test) can see when autograd stopped handing the tensors through unchanged.
 _CARRY_BF16 = os.environ.get("VITK_NO_SHADOW", "") == ""
+_CARRY_STATS = {"offered": 0, "taken": 0}
+
+
+def carry_stats(reset: bool = False) -> dict:
+    """{"offered": bf16 gradient copies attached by a sub-layer's backward, "taken": copies a consumer used in place of a
+    cast}.  In a plain stack of encoder blocks every offer but the first block's is taken."""
+    out = dict(_CARRY_STATS)
+    if reset:
+        _CARRY_STATS["offered"] = _CARRY_STATS["taken"] = 0
+    return out
 
 
 def _shadow_buffer(dx: Tensor, tc: torch.dtype, rows: Optional[Tensor]) -> Optional[Tensor]:
@@ -353,6 +370,7 @@ def _attach_bf16(dx: Tensor, shadow: Optional[Tensor]) -> Tensor:
     """``dx`` is the gradient about to be returned to autograd; ``shadow`` holds the same values in bf16 (flattened rows)."""
     if shadow is not None:
         dx._vitk_bf16 = (shadow, dx._version)   # the version tells an in-place accumulation into dx apart
+        _CARRY_STATS["offered"] += 1
     return dx
 
 
@@ -364,6 +382,7 @@ def _carried_bf16(dnew: Tensor, D: int) -> Optional[Tensor]:
     if (dnew._version != version or dnew.dtype != torch.float32 or not dnew.is_contiguous()
             or shadow.numel() != dnew.numel() or shadow.device != dnew.device):
         return None
+    _CARRY_STATS["taken"] += 1
     return shadow.view(-1, D)
 
 

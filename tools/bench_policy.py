@@ -1,6 +1,6 @@
 """A/B of the MFMA GEMM's tuning knobs (VitkGemm.store_policy, panel_m) on the encoder step's products with their real
 epilogues: variants are timed in interleaved rounds inside one process, median and minimum per variant.
-Usage: python tools/bench_policy.py [rounds] [case-substring]"""
+Usage: python tools/bench_policy.py [rounds] [case-substring]     (PANELS=8,4,16,...: a panel_m sweep at the default store policy)"""
 import os
 import statistics
 import sys
@@ -17,6 +17,8 @@ B, S, D, F = 256, 272, 768, 3072
 M = B * S
 dev = "cuda"
 VARIANTS = [(1, 8), (2, 8), (3, 8), (1, 4), (2, 4), (2, 6), (2, 12), (2, 16), (1, 16)]   # (store_policy, panel_m)
+if os.environ.get("PANELS"):
+    VARIANTS = [(0, int(v)) for v in os.environ["PANELS"].split(",")]
 
 
 def rnd(*shape, dtype=torch.bfloat16):
@@ -51,6 +53,7 @@ CASES = [
     ("fc1 + SwiGLU", "nt", M, 2 * F, D, "glu"), ("fc2 dgrad + DGLU", "nn", M, F, D, "dglu"), ("fc2 + residual", "nt", M, D, F, "res"),
     ("out + residual", "nt", M, D, D, "res"), ("qkv fwd", "nt", M, 3 * D, D, "bias"), ("fc1 dgrad", "nn", M, D, 2 * F, "store"),
     ("qkv dgrad", "nn", M, D, 3 * D, "store"), ("fc1 wgrad", "tn", 2 * F, D, M, "wgrad"), ("fc2 wgrad", "tn", D, F, M, "wgrad"),
+    ("qkv wgrad", "tn", 3 * D, D, M, "wgrad"), ("out wgrad", "tn", D, D, M, "wgrad"), ("out dgrad", "nn", M, D, D, "store"),
 ]
 for spec in CASES:
     if ONLY and ONLY not in spec[0]:

@@ -1,5 +1,5 @@
 """Reads the per-segment cycle sums an EXP_STAMP build of gemm_mfma256d_k keeps (diagnostics only):
-VITK_LIB=exp/libvitk_stamp.so python tools/stamp_gemm.py [store|glu|dglu|res|out|fc2]"""
+VITK_LIB=exp/libvitk_stamp.so python tools/stamp_gemm.py [store|glu|dglu|res|out|fc2|wgrad1|wgrad2|wgradq|nn1|nnq]"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -21,6 +21,14 @@ elif mode in ("out", "fc2"):   # narrow outputs: N = D, K = D or F, plain bf16 s
     a = rnd(M, kk)
     w, out = rnd(D, kk), torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
     run = lambda: K.gemm(a, w, trans_a=False, trans_b=False, M=M, N=D, K=kk, out=out, algo=5)
+elif mode.startswith("wgrad"):   # weight gradients: dW[n_out, n_in] = dy^T @ x, contraction over the M rows, split-K partials
+    n_out, n_in = {"wgrad1": (2 * F, D), "wgrad2": (D, F), "wgradq": (3 * D, D)}[mode]
+    dy, x, out = rnd(M, n_out), rnd(M, n_in), torch.empty(n_out, n_in, device="cuda")
+    run = lambda: K.gemm(dy, x, trans_a=True, trans_b=True, M=n_out, N=n_in, K=M, out=out, algo=5)
+elif mode.startswith("nn"):      # input gradients: dx[M, n_in] = dy[M, n_out] @ W[n_out, n_in]
+    n_out, n_in = {"nn1": (2 * F, D), "nnq": (3 * D, D)}[mode]
+    dy, w, out = rnd(M, n_out), rnd(n_out, n_in), torch.empty(M, n_in, device="cuda", dtype=torch.bfloat16)
+    run = lambda: K.gemm(dy, w, trans_a=False, trans_b=True, M=M, N=n_in, K=n_out, out=out, algo=5)
 elif mode == "res":
     a = rnd(M, F)
     w, out, res = rnd(D, F), torch.empty(M, D, device="cuda"), torch.randn(M, D, device="cuda")

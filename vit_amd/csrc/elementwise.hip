@@ -792,6 +792,37 @@ __global__ __launch_bounds__(256) void im2col_k(const TX* x_in, TX* x_out, const
   }
 }
 
+// Unfolding one band of patches (one image, one row of the patch grid) per workgroup: the band's ph image rows of every
+// channel are read along W (whole cache lines), converted and laid out in LDS as the band's gw output rows, which are one
+// contiguous range of the output and leave with 16-byte stores.  The element-indexed kernel above reads pw-element runs
+// (56 bytes at pw = 14) and fetched 3x the image from memory.
+template <class TX, class TC>
+__global__ __launch_bounds__(256) void im2col_band_k(const TX* __restrict__ x, TC* __restrict__ cols, int64_t C, int64_t H,
+                                                     int64_t W, int ph, int pw, int ldc, int gh, int gw) {
+  extern __shared__ __attribute__((aligned(16))) char band_smem[];
+  TC* band = (TC*)band_smem;
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x / gh;
+  const int ii = (int)(blockIdx.x % gh);
+  const int K = (int)C * ph * pw, wc = gw * pw, n = gw * ldc;
+  if (ldc > K)
+    for (int i = tid; i < gw * (ldc - K); i += 256) band[(i / (ldc - K)) * ldc + K + i % (ldc - K)] = from_f<TC>(0.f);
+  const int per_c = ph * wc;
+  for (int i = tid; i < (int)C * per_c; i += 256) {
+    const int c = i / per_c, r = i - c * per_c, u = r / wc, xx = r - u * wc;
+    const int j = xx / pw, v = xx - j * pw;
+    band[j * ldc + (c * ph + u) * pw + v] = from_f<TC>(to_f<TX>(x[((b * C + c) * H + (int64_t)ii * ph + u) * W + xx]));
+  }
+  __syncthreads();
+  TC* dst = cols + (int64_t)blockIdx.x * n;
+  constexpr int V = 16 / sizeof(TC);
+  if ((((uintptr_t)dst) & 15) == 0 && n % V == 0) {
+    for (int i = tid; i < n / V; i += 256) ((uint4*)dst)[i] = ((const uint4*)band)[i];
+  } else {
+    for (int i = tid; i < n; i += 256) dst[i] = band[i];
+  }
+}
+
 // rows/columns of the image that no patch covers (H % ph, W % pw) get a zero gradient
 template <class TX>
 __global__ __launch_bounds__(256) void zero_uncovered_k(TX* dx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t Hc,
@@ -811,6 +842,18 @@ extern "C" int vitk_im2col(const void* x, int x_dtype, void* cols, int cols_dtyp
   if (total == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ew_grid(total)), block(256);
+  const int64_t gh = H / ph, gw = W / pw;
+  const size_t band_bytes = (size_t)gw * ldc * (cols_dtype == VITK_F32 ? 4 : 2);
+  if (band_bytes <= 64 * 1024 && B * gh < (int64_t)1 << 31 && gw * ldc < (int64_t)1 << 30) {
+    DISPATCH_DTYPE(x_dtype, TX, {
+      DISPATCH_DTYPE(cols_dtype, TC, {
+        hipLaunchKernelGGL((im2col_band_k<TX, TC>), dim3((unsigned)(B * gh)), block, band_bytes, st, (const TX*)x, (TC*)cols, C,
+                           H, W, (int)ph, (int)pw, (int)ldc, (int)gh, (int)gw);
+      });
+    });
+    VITK_LAUNCH_CHECK("im2col");
+    return 0;
+  }
   DISPATCH_DTYPE(x_dtype, TX, {
     DISPATCH_DTYPE(cols_dtype, TC, {
       hipLaunchKernelGGL((im2col_k<TX, TC, false>), grid, block, 0, st, (const TX*)x, (TX*)nullptr, (const TC*)nullptr,

@@ -139,14 +139,18 @@ typedef struct VitkGemm {
   float* qk_mean;
   float qk_eps;
   int32_t qk_layernorm;
-  /* Tuning knobs of the MFMA kernels; 0 = the library's choice (what production callers pass).
-   *   store_policy  1: the epilogue's 16-byte output stores are plain (their lines stay in the XCD's L2);
-   *                 2: they are written through (sc1: the line is not kept, so a tile's output does not push the operand
-   *                    panels of the neighbouring tiles out of the 4 MiB L2);
-   *                 3: as 2, and the epilogue's read-once rows (saved pre-activations, residual rows) are asked for
-   *                    with the streaming (nt) policy.
+  /* Tuning knobs of the MFMA kernels; 0 = the library's choice (what production callers pass).  They exist for A/B
+   * measurements (tools/bench_policy.py); neither changes a result.
+   *   store_policy  1: every epilogue output store is plain (its lines stay in the XCD's L2);
+   *                 2: the 16-byte output stores of the activation-backward epilogues (DGLU, DACT) are written through
+   *                    (sc1: the line is not kept in L2); the other epilogues' stores stay plain (write-through stores
+   *                    measured slower on them);
+   *                 3: as 2, and the register path of the epilogues asks for its read-once rows (saved pre-activations,
+   *                    residual rows) with the streaming (nt) policy.
+   *                 0 behaves as 1 unless the environment sets VITK_WT_STORES=1.
    *   panel_m       row tiles per panel of the tile walk (tiles are walked panel by panel, column tile by column tile
-   *                 inside a panel, so that a panel's A rows stay in L2 across its column tiles). */
+   *                 inside a panel, so that a panel's A rows stay in L2 across its column tiles).  0: 4 when the output
+   *                 is at most four 256-column tiles wide, 8 otherwise. */
   int32_t store_policy;
   int32_t panel_m;
 } VitkGemm;

@@ -91,12 +91,19 @@ class BucketedGradAllReduce:
         self.buckets: List[_Bucket] = []
         cur: List[torch.nn.Parameter] = []
         size = 0
+        # The gradients that arrive last (the first layers) have the least backward left to hide their all-reduce behind:
+        # the last `bucket_bytes` of the walk go out in buckets a quarter the size, so that only the final small bucket
+        # is queued at the very end of backward instead of a full one.
+        left = sum(p.numel() * p.element_size() for p in plist)
         for p in reversed(plist):
-            if cur and (size + p.numel() * p.element_size() > bucket_bytes or p.dtype != cur[0].dtype):
+            nbytes = p.numel() * p.element_size()
+            cap = bucket_bytes if left > bucket_bytes else max(bucket_bytes // 4, min(bucket_bytes, 1 << 20))
+            if cur and (size + nbytes > cap or p.dtype != cur[0].dtype):
                 self.buckets.append(_Bucket(cur))
                 cur, size = [], 0
             cur.append(p)
-            size += p.numel() * p.element_size()
+            size += nbytes
+            left -= nbytes
         if cur:
             self.buckets.append(_Bucket(cur))
         self._where = {}

@@ -170,6 +170,29 @@ def make_op_level(ref):
     print(f"{'g07_ops':45s} bytes={os.path.getsize(path)}")
 
 
+MASK_CASES = [   # (grid, mask_ratio, batch, scale, roll, seed)
+    ((16, 16), 0.25, 3, 1, False, 11), ((14, 10), 0.6, 2, 1, False, 12), ((16, 16), 0.5, 4, 2, False, 13),
+    ((16, 16), 0.4, 5, 2, True, 14), ((24,), 0.3, 2, 1, False, 15), ((12, 12), 0.75, 3, 4, True, 16),
+]
+
+
+def make_masks(ref):
+    """Token masks drawn by the reference from a seeded default CPU generator (vit/tokens.py:107-218): create_mask with and
+    without block scale / roll, and a non-overlapping second mask drawn right after the first."""
+    from vit.tokens import create_mask, generate_non_overlapping_mask
+
+    fix = {"cases": []}
+    for size, ratio, B, scale, roll, seed in MASK_CASES:
+        torch.manual_seed(seed)
+        mask = create_mask(size, ratio, batch_size=B, scale=scale, roll=roll)
+        second = generate_non_overlapping_mask(~mask, ratio, 0.2) if ratio + 0.2 <= 1 else None
+        fix["cases"].append({"size": tuple(size), "mask_ratio": ratio, "batch": B, "scale": scale, "roll": roll, "seed": seed,
+                             "mask": mask, "second_p2": 0.2, "second": second})
+    path = os.path.join(OUT, "g16_masks.pt")
+    torch.save(fix, path)
+    print(f"{'g16_masks':45s} bytes={os.path.getsize(path)}")
+
+
 HEAD_CASES = {
     # name -> (backbone overrides, mode)
     "g12_heads_fp32": (dict(activation="swiglu", pos_enc="fourier", num_register_tokens=2), "fp32"),
@@ -271,6 +294,8 @@ def main():
         make(ref, name, ov, B, hw, mode, seed=1000 + i)
     if not only or any("g07_ops".startswith(p) for p in only):
         make_op_level(ref)
+    if not only or any("g16_masks".startswith(p) for p in only):
+        make_masks(ref)
     for i, (name, (ov, mode)) in enumerate(HEAD_CASES.items()):
         if only and not any(name.startswith(p) for p in only):
             continue

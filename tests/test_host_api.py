@@ -242,6 +242,25 @@ def test_create_mask_drops_the_requested_share(size, ratio, scale, roll):
         create_mask(size, 1.5)
 
 
+def test_masks_follow_the_references_random_stream():
+    """tests/golden/g16_masks.pt: masks the live reference drew from a seeded CPU generator (oracle/gen_golden.py:make_masks;
+    vit/tokens.py:107-218).  The same seed here draws the same masks, block scale, roll and the non-overlapping second
+    mask included."""
+    import os
+
+    from vit_amd.tokens import create_mask, generate_non_overlapping_mask
+
+    fix = torch.load(os.path.join(os.path.dirname(__file__), "golden", "g16_masks.pt"), weights_only=True)
+    assert len(fix["cases"]) >= 6
+    for c in fix["cases"]:
+        torch.manual_seed(c["seed"])
+        mask = create_mask(c["size"], c["mask_ratio"], batch_size=c["batch"], scale=c["scale"], roll=c["roll"])
+        assert torch.equal(mask, c["mask"]), (c["size"], c["scale"], c["roll"])
+        if c["second"] is not None:
+            second = generate_non_overlapping_mask(~mask, c["mask_ratio"], c["second_p2"])
+            assert torch.equal(second, c["second"]), c["size"]
+
+
 def test_generate_non_overlapping_mask():   # tests/test_tokens.py:147-170
     from vit_amd.tokens import create_mask, generate_non_overlapping_mask
 

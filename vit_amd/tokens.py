@@ -66,7 +66,8 @@ def create_mask(size: Sequence[int], mask_ratio: float, batch_size: int = 1, sca
     """Random mask over a token grid: exactly round(L * mask_ratio) tokens dropped per sample, chosen
     independently per sample (vit/tokens.py:107-175).  scale > 1 draws the mask on the grid shrunk by ``scale`` and
     enlarges it, so tokens are dropped in scale x scale blocks; ``roll`` shifts half of those samples by scale // 2.
-    The draw uses its own sequence of random calls: same distribution as the reference, not the same stream."""
+    The random calls follow the reference's order, so a seeded generator draws the reference's mask (pinned by
+    tests/golden/g16_masks.pt on the CPU generator)."""
     if not 0 < mask_ratio < 1.0:
         raise ValueError(f"Invalid `mask_ratio` {mask_ratio}")
     if scale < 1:
@@ -89,9 +90,12 @@ def create_mask(size: Sequence[int], mask_ratio: float, batch_size: int = 1, sca
     for s in size:
         total *= int(s)
     dropped = int(torch.tensor(total * mask_ratio).round().item())
-    # the `dropped` smallest of L independent uniform scores: a uniformly random subset per sample
-    scores = torch.rand(batch_size, total, device=device)
-    drop_pos = torch.argsort(scores, dim=1)[:, :dropped]
+    # The random calls, in the reference's order, so that a seeded generator yields the reference's mask: one permutation
+    # of the positions shared by all samples, then a [B, L] block of uniforms whose per-sample ranking picks which entries
+    # of that permutation are dropped.
+    order = torch.randperm(total, device=device)
+    ranks = torch.argsort(torch.rand(batch_size, total, device=device, dtype=torch.float32), dim=-1)[:, :dropped]
+    drop_pos = order[ranks]
     mask = torch.ones(batch_size, total, dtype=torch.bool, device=device)
     mask.scatter_(1, drop_pos, False)
     return mask

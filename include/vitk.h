@@ -52,6 +52,18 @@ int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, cons
                   const float* rstd, const float* mean, const void* add, void* dx, int dx_dtype, void* dw, void* db,
                   const int64_t* row_idx, int64_t rows, int64_t D, int is_layernorm, void* workspace, void* dx_bf16, void* stream);
 
+/* Backward of the per-head normalisation of q and k (vit/attention.py:25-41, applied at :95-105), in place on the packed
+ * gradient dqkv [M, ld] whose first two sections of H * Dh columns hold the gradients of the normalised q and k heads:
+ * each head row is replaced by the gradient of the un-normalised head.  pre_q / pre_k [M * H, Dh] (dtype of dqkv) are the
+ * heads before normalisation, rstd / mean [M * H] their row statistics (mean NULL for RMSNorm), w_q / w_k [Dh] the weights.
+ * dw / db [Dh] (dtype w_dtype; NULL for a frozen parameter) are summed through `workspace`
+ * (vitk_qk_norm_bwd_workspace_bytes(Dh)).  head_dim: a multiple of 8, at most 128. */
+size_t vitk_qk_norm_bwd_workspace_bytes(int64_t Dh);
+int vitk_qk_norm_bwd(void* dqkv, int dtype, const void* pre_q, const void* pre_k, const float* rstd_q, const float* rstd_k,
+                     const float* mean_q, const float* mean_k, const void* w_q, const void* w_k, int w_dtype, void* dw_q,
+                     void* db_q, void* dw_k, void* db_k, int64_t M, int64_t H, int64_t Dh, int64_t ld, int is_layernorm,
+                     void* workspace, void* stream);
+
 /* ---- GEMM: F.linear at vit/attention.py:93,213, vit/fused.py:114,117,153,164, the conv of
  *      vit/patch_embed.py:54 (as im2col GEMM), and their autograd backward (dgrad / wgrad) -------
  * C[M,N] = op(A) x op(B), fp32 accumulate.

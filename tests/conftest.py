@@ -28,8 +28,10 @@ def load_golden(name: str) -> dict:
 
 
 def golden_names() -> list[str]:
-    """Encoder fixtures (g07_ops holds op-level vectors, g12_* the head fixtures, g13_* the decoder-layer fixtures)."""
-    return sorted(f[:-3] for f in os.listdir(GOLDEN) if f.endswith(".pt") and f != "g07_ops.pt" and not f.startswith(("g12_", "g13_")))
+    """Encoder fixtures (g07_ops holds op-level vectors, g12_* the head fixtures, g13_* the decoder-layer fixtures, g16_masks
+    the token masks)."""
+    return sorted(f[:-3] for f in os.listdir(GOLDEN)
+                  if f.endswith(".pt") and f not in ("g07_ops.pt", "g16_masks.pt") and not f.startswith(("g12_", "g13_")))
 
 
 def layer_golden_names() -> list[str]:

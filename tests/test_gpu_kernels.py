@@ -460,6 +460,59 @@ def test_gemm_rope_epilogue_equals_projection_then_rotation(shape, algo, emu):
     assert not torch.equal(got, plain)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("layernorm", [False, True])
+@pytest.mark.parametrize("shape", [(37, 3, 64), (5, 2, 80), (130, 4, 88), (1, 1, 128), (600, 12, 64)])
+def test_per_head_qk_norm_backward_in_place(shape, layernorm, dtype):
+    """vitk_qk_norm_bwd rewrites the q and k sections of a packed gradient [M, 3, H, Dh] in place, from the gradient of the
+    normalised heads to the gradient of the heads, and sums the weight / bias gradients (vit/attention.py:25-41 through
+    autograd, in fp64); the v section is left alone."""
+    M, H, Dh = shape
+    dt = getattr(torch, dtype)
+    D = H * Dh
+    g = torch.Generator(device="cpu").manual_seed(M * 131 + Dh)
+    dqkv = torch.randn(M, 3 * D, generator=g).to(dt).cuda()
+    pre = [(torch.randn(M * H, Dh, generator=g) * 1.5 + 0.3).to(dt).cuda() for _ in range(2)]
+    w = [(1 + 0.2 * torch.randn(Dh, generator=g)).cuda() for _ in range(2)]
+    eps = 1e-5
+    want_sections, want_dw, want_db, stats = [], [], [], []
+    for which in range(2):
+        x = pre[which].double().requires_grad_(True)
+        wd = w[which].double().requires_grad_(True)
+        bd = torch.zeros(Dh, dtype=torch.float64, device="cuda", requires_grad=True)
+        if layernorm:
+            y = torch.nn.functional.layer_norm(x, (Dh,), wd, bd, eps)
+            mean = x.detach().mean(-1)
+            rstd = (x.detach().var(-1, unbiased=False) + eps).rsqrt()
+        else:
+            y = torch.nn.functional.rms_norm(x, (Dh,), wd, eps)
+            mean = None
+            rstd = (x.detach().square().mean(-1) + eps).rsqrt()
+        dpost = dqkv[:, which * D:(which + 1) * D].reshape(M * H, Dh).double()
+        y.backward(dpost)
+        want_sections.append(x.grad.view(M, D))
+        want_dw.append(wd.grad)
+        want_db.append(bd.grad if layernorm else None)
+        stats.append((rstd.float(), None if mean is None else mean.float()))
+    got = dqkv.clone()
+    outs = K.qk_norm_bwd_(got, pre[0], pre[1], stats[0][0], stats[1][0], stats[0][1], stats[1][1], w[0], w[1], H, Dh, layernorm,
+                          (True, layernorm, True, layernorm))
+    rtol = 1e-4 if dt == torch.float32 else 2e-2
+    for which in range(2):
+        close(got[:, which * D:(which + 1) * D].double(), want_sections[which], rtol, msg=f"section {which}")
+        close(outs[2 * which].double(), want_dw[which], rtol if dt == torch.float32 else 1e-2, msg=f"dw {which}")
+        if layernorm:
+            close(outs[2 * which + 1].double(), want_db[which], rtol if dt == torch.float32 else 1e-2, msg=f"db {which}")
+        else:
+            assert outs[2 * which + 1] is None
+    assert torch.equal(got[:, 2 * D:], dqkv[:, 2 * D:])
+    # frozen norm parameters: no workspace, same rows
+    again = dqkv.clone()
+    none = K.qk_norm_bwd_(again, pre[0], pre[1], stats[0][0], stats[1][0], stats[0][1], stats[1][1], w[0], w[1], H, Dh, layernorm,
+                          (False, False, False, False))
+    assert none == (None, None, None, None) and torch.equal(again, got)
+
+
 @pytest.mark.parametrize("with_rope", [False, True])
 @pytest.mark.parametrize("layernorm", [False, True])
 @pytest.mark.parametrize("shape", [(3, 37, 2, 5), (40, 197, 6, 1), (256, 272, 12, 16)])

@@ -17,6 +17,7 @@ ACT_CODES = {"relu": 0, "reglu": 0, "silu": 1, "swiglu": 1, "gelu": 2, "geglu": 
 
 EXPORTS = [
     "vitk_version", "vitk_last_error", "vitk_norm_fwd", "vitk_norm_bwd", "vitk_norm_bwd_workspace_bytes",
+    "vitk_qk_norm_bwd", "vitk_qk_norm_bwd_workspace_bytes",
     "vitk_gemm", "vitk_gemm_workspace_bytes", "vitk_attn_fwd", "vitk_attn_bwd", "vitk_attn_weights", "vitk_rope_qk", "vitk_rope_rows", "vitk_debug_hold_cus", "vitk_act_fwd",
     "vitk_act_bwd", "vitk_im2col", "vitk_col2im", "vitk_colsum", "vitk_colsum_static", "vitk_colsum_workspace_bytes", "vitk_scale_cast",
     "vitk_prefix_fill", "vitk_copy_samples", "vitk_fourier_features", "vitk_fourier_features_bwd",
@@ -76,7 +77,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.vitk_last_error.restype = C.c_char_p
     lib.vitk_version.restype = C.c_int
-    for name in ("vitk_norm_bwd_workspace_bytes", "vitk_colsum_workspace_bytes"):
+    for name in ("vitk_norm_bwd_workspace_bytes", "vitk_colsum_workspace_bytes", "vitk_qk_norm_bwd_workspace_bytes"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_int64]
     lib.vitk_gemm_workspace_bytes.restype = C.c_size_t
@@ -85,6 +86,7 @@ def load() -> C.CDLL:
     sigs = {
         "vitk_norm_fwd": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i64, i64, f32, i32, vp],
         "vitk_norm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, vp, vp],
+        "vitk_qk_norm_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp, vp],
         "vitk_gemm": [C.POINTER(VitkGemm), vp],
         "vitk_attn_fwd": [C.POINTER(VitkAttn), vp],
         "vitk_attn_bwd": [C.POINTER(VitkAttn), vp],

@@ -409,6 +409,33 @@ extern "C" size_t vitk_norm_bwd_workspace_bytes(int64_t D) {
   return (size_t)(NORM_BWD_BLOCKS + NORM_BWD_FOLD) * 2 * (size_t)D * sizeof(float);
 }
 
+// fold the per-block partials [grid][2][D] (dw = first half, db = second half) of a norm backward in two steps, so that
+// the first one has enough blocks in flight: [grid] -> [NORM_BWD_FOLD] rows (behind the partials in the workspace) -> 1 row
+static void fold_rows(const float* ws, int grid, int64_t D, int w_dtype, void* dw, void* db, float* ws2, hipStream_t st) {
+  const int fold = grid > 4 * NORM_BWD_FOLD ? NORM_BWD_FOLD : 1;
+  for (int which = 0; which < 2; which++) {
+    void* dst = which == 0 ? dw : db;
+    if (!dst) continue;
+    const float* src = ws + (size_t)which * D;
+    int64_t src_ld = 2 * D, src_rows = grid;
+    if (fold > 1) {
+      dim3 g1((unsigned)ceil_div(D, 256), (unsigned)fold);
+      colsum_one<float, float, float>(true, g1, st, src, src_ld, nullptr, (const float*)nullptr, 0, ws2 + (size_t)which * D,
+                                      2 * D, src_rows, D, 1.f);
+      src = ws2 + (size_t)which * D;
+      src_rows = fold;
+    }
+    dim3 g2((unsigned)ceil_div(D, 256), 1);
+    if (w_dtype == VITK_F32)
+      colsum_one<float, float, float>(true, g2, st, src, src_ld, nullptr, (const float*)nullptr, 0, (float*)dst, D, src_rows, D, 1.f);
+    else
+      colsum_one<float, float, bf16>(true, g2, st, src, src_ld, nullptr, (const float*)nullptr, 0, (bf16*)dst, D, src_rows, D, 1.f);
+  }
+}
+static void fold_norm_partials(float* ws, int grid, int64_t D, int w_dtype, void* dw, void* db, hipStream_t st) {
+  fold_rows(ws, grid, D, w_dtype, dw, db, ws + (size_t)NORM_BWD_BLOCKS * 2 * D, st);
+}
+
 template <class TG, class TX, class TW, class TO, bool LN>
 static int norm_bwd_launch(const void* dy, const void* x, const void* w, const float* rstd, const float* mean,
                            const void* add, void* dx, const int64_t* idx, int64_t rows, int D, float* ws, int want_dw,
@@ -477,29 +504,7 @@ extern "C" int vitk_norm_bwd(const void* dy, int dy_dtype, const void* x, int x_
   if (rc) return rc;
   VITK_LAUNCH_CHECK("norm_bwd");
   if (want_dw) {
-    // fold the per-block partials [grid][2][D] (dw = first half, db = second half) in two steps, so that the first
-    // one has enough blocks in flight: [grid] -> [NORM_BWD_FOLD] rows (after the partials in the workspace) -> 1 row
-    float* ws = (float*)workspace;
-    float* ws2 = ws + (size_t)NORM_BWD_BLOCKS * 2 * D;
-    const int fold = grid > 4 * NORM_BWD_FOLD ? NORM_BWD_FOLD : 1;
-    for (int which = 0; which < 2; which++) {
-      void* dst = which == 0 ? dw : db;
-      if (!dst) continue;
-      const float* src = ws + (size_t)which * D;
-      int64_t src_ld = 2 * D, src_rows = grid;
-      if (fold > 1) {
-        dim3 g1((unsigned)ceil_div(D, 256), (unsigned)fold);
-        colsum_one<float, float, float>(true, g1, st, src, src_ld, nullptr, (const float*)nullptr, 0, ws2 + (size_t)which * D,
-                                        2 * D, src_rows, D, 1.f);
-        src = ws2 + (size_t)which * D;
-        src_rows = fold;
-      }
-      dim3 g2((unsigned)ceil_div(D, 256), 1);
-      if (w_dtype == VITK_F32)
-        colsum_one<float, float, float>(true, g2, st, src, src_ld, nullptr, (const float*)nullptr, 0, (float*)dst, D, src_rows, D, 1.f);
-      else
-        colsum_one<float, float, bf16>(true, g2, st, src, src_ld, nullptr, (const float*)nullptr, 0, (bf16*)dst, D, src_rows, D, 1.f);
-    }
+    fold_norm_partials((float*)workspace, grid, D, w_dtype, dw, db, st);
     VITK_LAUNCH_CHECK("norm_bwd reduce");
   }
   return 0;
@@ -767,6 +772,136 @@ extern "C" int vitk_rope_rows(void* x, int dtype, const float* table, int64_t B,
 extern "C" int vitk_rope_qk(void* qkv, int dtype, const float* table, int64_t B, int64_t S, int64_t H, int64_t Dh,
                             int64_t prefix, int inverse, int emulate_bf16, int per_sample, void* stream) {
   return vitk_rope_rows(qkv, dtype, table, B, S, H, Dh, prefix, 3 * H * Dh, 2, inverse, emulate_bf16, per_sample, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the per-head q / k normalisation (vit/attention.py:25-41) in place on the packed gradient [M, 3, H, Dh]:
+// sections 0 (q) and 1 (k) of every row hold H head rows of Dh values each; the gradient with respect to the normalised
+// head is replaced by the gradient with respect to the un-normalised one, and the weight / bias gradients are summed.
+// 16 lanes own a head row (8 values per lane, lanes past Dh / 8 idle), so a wave handles four head rows at a time and no
+// head is ever copied out into a matrix of its own.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <class T, class TW, bool LN>
+__global__ __launch_bounds__(256) void qk_norm_bwd_k(T* dqkv, const T* __restrict__ pre_q, const T* __restrict__ pre_k,
+                                                     const float* __restrict__ rstd_q, const float* __restrict__ rstd_k,
+                                                     const float* __restrict__ mean_q, const float* __restrict__ mean_k,
+                                                     const TW* __restrict__ w_q, const TW* __restrict__ w_k, int64_t M, int H,
+                                                     int Dh, int64_t ld, float* __restrict__ partial /* [2][grid][2][Dh] */) {
+  __shared__ float red[16][2][128];   // one slot per 16-lane group of the workgroup
+  const int which = blockIdx.y;       // 0: q, 1: k
+  const T* pre = which ? pre_k : pre_q;
+  const float* rstd_in = which ? rstd_k : rstd_q;
+  const float* mean_in = which ? mean_k : mean_q;
+  const TW* w = which ? w_k : w_q;
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int d = sub * 8;
+  const bool on = d < Dh;
+  const float invD = 1.f / (float)Dh;
+  float wv[8], aw[8], ab[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { wv[i] = on ? to_f<TW>(w[d + i]) : 0.f; aw[i] = 0.f; ab[i] = 0.f; }
+  const int64_t rows = M * H;
+  for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
+    const int64_t r = r0 + grp;
+    const bool live = on && r < rows;
+    const int64_t m = r / H;
+    const int h = (int)(r - m * H);
+    T* g = dqkv + m * ld + (int64_t)which * H * Dh + (int64_t)h * Dh + d;
+    float gv[8], xh[8];
+    float c1 = 0.f, c2 = 0.f, rstd = 0.f;
+    if (live) {
+      Vec4<T> g0, g1, x0, x1;
+      g0.load(g); g1.load(g + 4);
+      x0.load(pre + r * Dh + d); x1.load(pre + r * Dh + d + 4);
+      rstd = rstd_in[r];
+      const float mean = LN ? mean_in[r] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float gi = i < 4 ? g0.v[i] : g1.v[i - 4], xi = i < 4 ? x0.v[i] : x1.v[i - 4];
+        xh[i] = (xi - mean) * rstd;
+        gv[i] = gi * wv[i];
+        c1 += gv[i];
+        c2 += gv[i] * xh[i];
+        aw[i] += gi * xh[i];
+        ab[i] += gi;
+      }
+    }
+    c2 = sum16(c2) * invD;
+    c1 = LN ? sum16(c1) * invD : 0.f;
+    if (live) {
+      Vec4<T> o0, o1;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float o = rstd * (gv[i] - c1 - xh[i] * c2);
+        if (i < 4) o0.v[i] = o; else o1.v[i - 4] = o;
+      }
+      o0.store(g); o1.store(g + 4);
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { red[grp][0][d + i] = aw[i]; red[grp][1][d + i] = ab[i]; }
+  __syncthreads();
+  float* prow = partial + ((size_t)which * gridDim.x + blockIdx.x) * 2 * Dh;
+  for (int i = threadIdx.x; i < 2 * Dh; i += 256) {
+    const int half = i / Dh, c = i - half * Dh;
+    float sacc = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; g2++) sacc += red[g2][half][c];
+    prow[i] = sacc;
+  }
+}
+
+extern "C" size_t vitk_qk_norm_bwd_workspace_bytes(int64_t Dh) { return 2 * vitk_norm_bwd_workspace_bytes(Dh); }
+
+extern "C" int vitk_qk_norm_bwd(void* dqkv, int dtype, const void* pre_q, const void* pre_k, const float* rstd_q,
+                                const float* rstd_k, const float* mean_q, const float* mean_k, const void* w_q,
+                                const void* w_k, int w_dtype, void* dw_q, void* db_q, void* dw_k, void* db_k, int64_t M,
+                                int64_t H, int64_t Dh, int64_t ld, int is_layernorm, void* workspace, void* stream) {
+  VITK_REQUIRE(dqkv && pre_q && pre_k && rstd_q && rstd_k && w_q && w_k, "qk_norm_bwd: null pointer");
+  VITK_REQUIRE(!is_layernorm || (mean_q && mean_k), "qk_norm_bwd: LayerNorm needs the saved means");
+  VITK_REQUIRE(M >= 0 && H > 0 && Dh > 0 && Dh % 8 == 0 && Dh <= 128, "qk_norm_bwd: head_dim=%lld must be a multiple of 8, at most 128",
+               (long long)Dh);
+  VITK_REQUIRE(ld >= 2 * H * Dh && ld % 4 == 0, "qk_norm_bwd: ld=%lld too small for two sections of %lld heads", (long long)ld, (long long)H);
+  VITK_REQUIRE(dtype == VITK_F32 || dtype == VITK_BF16, "qk_norm_bwd: bad dtype");
+  const bool want = dw_q || db_q || dw_k || db_k;
+  VITK_REQUIRE(!want || workspace, "qk_norm_bwd: workspace required for the weight gradients");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t wbytes = (size_t)Dh * (w_dtype == VITK_F32 ? 4 : 2);
+  if (M == 0) {
+    for (void* p : {dw_q, db_q, dw_k, db_k})
+      if (p) (void)hipMemsetAsync(p, 0, wbytes, st);
+    return 0;
+  }
+  int grid = (int)std::min<int64_t>(ceil_div(M * H, 16), NORM_BWD_BLOCKS);
+  float* ws = (float*)workspace;
+  float* part = want ? ws : nullptr;
+  DISPATCH_DTYPE(dtype, T, {
+    DISPATCH_DTYPE(w_dtype, TW, {
+      if (is_layernorm)
+        hipLaunchKernelGGL((qk_norm_bwd_k<T, TW, true>), dim3(grid, 2), dim3(256), 0, st, (T*)dqkv, (const T*)pre_q, (const T*)pre_k,
+                           rstd_q, rstd_k, mean_q, mean_k, (const TW*)w_q, (const TW*)w_k, M, (int)H, (int)Dh, ld, part);
+      else
+        hipLaunchKernelGGL((qk_norm_bwd_k<T, TW, false>), dim3(grid, 2), dim3(256), 0, st, (T*)dqkv, (const T*)pre_q, (const T*)pre_k,
+                           rstd_q, rstd_k, mean_q, mean_k, (const TW*)w_q, (const TW*)w_k, M, (int)H, (int)Dh, ld, part);
+    });
+  });
+  VITK_LAUNCH_CHECK("qk_norm_bwd");
+  if (want) {
+    // section 1's partials follow section 0's grid rows directly; fold each with its own scratch rows
+    float* s0 = ws;
+    float* s1 = ws + (size_t)grid * 2 * Dh;
+    float* scratch = ws + (size_t)2 * NORM_BWD_BLOCKS * 2 * Dh;   // two folds' worth of intermediate rows, behind both sections' partials
+    fold_rows(s0, grid, Dh, w_dtype, dw_q, db_q, scratch, st);
+    fold_rows(s1, grid, Dh, w_dtype, dw_k, db_k, scratch + (size_t)NORM_BWD_FOLD * 2 * Dh, st);
+    VITK_LAUNCH_CHECK("qk_norm_bwd reduce");
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,6 +111,32 @@ def norm_bwd(dy: Tensor, x2: Tensor, w: Tensor, rstd: Tensor, mean: Optional[Ten
     return dw, db
 
 
+def can_qk_norm_bwd_inplace(dqkv: Tensor, Dh: int) -> bool:
+    return dqkv.is_contiguous() and Dh % 8 == 0 and Dh <= 128 and dqkv.dtype in (torch.float32, torch.bfloat16)
+
+
+def qk_norm_bwd_(dqkv: Tensor, pre_q: Tensor, pre_k: Tensor, rstd_q: Tensor, rstd_k: Tensor, mean_q: Optional[Tensor],
+                 mean_k: Optional[Tensor], w_q: Tensor, w_k: Tensor, H: int, Dh: int, layernorm: bool, want: tuple):
+    """In place on the packed gradient [M, 3 * H * Dh]: sections q and k go from the gradient of the normalised heads to
+    the gradient of the heads themselves.  ``want`` = (dw_q, db_q, dw_k, db_k) flags; returns those four (or None)."""
+    lib = L.load()
+    L.require_gpu(dqkv, pre_q, pre_k, w_q, w_k)
+    M = dqkv.shape[0]
+    assert dqkv.is_contiguous() and pre_q.is_contiguous() and pre_k.is_contiguous() and pre_q.dtype == dqkv.dtype == pre_k.dtype
+    assert pre_q.numel() == M * H * Dh == pre_k.numel() and w_q.dtype == w_k.dtype
+    outs = [torch.empty_like(w_q) if (f and (i % 2 == 0 or layernorm)) else None for i, f in enumerate(want)]
+    # the kernel sums weight and bias gradients together: a wanted bias gradient needs its weight slot too
+    slots = list(outs)
+    for i in (0, 2):
+        if slots[i] is None and slots[i + 1] is not None:
+            slots[i] = torch.empty_like(w_q)
+    ws = _workspace(lib.vitk_qk_norm_bwd_workspace_bytes(Dh), dqkv.device) if any(t is not None for t in slots) else None
+    L.check(lib.vitk_qk_norm_bwd(L.ptr(dqkv), L.dt(dqkv), L.ptr(pre_q), L.ptr(pre_k), L.ptr(rstd_q), L.ptr(rstd_k), L.ptr(mean_q),
+                                 L.ptr(mean_k), L.ptr(_c(w_q)), L.ptr(_c(w_k)), L.dt(w_q), L.ptr(slots[0]), L.ptr(slots[1]),
+                                 L.ptr(slots[2]), L.ptr(slots[3]), M, H, Dh, dqkv.shape[1], int(layernorm), L.ptr(ws), L.stream()))
+    return tuple(outs)
+
+
 def gemm(a: Tensor, b: Tensor, *, trans_a: bool, trans_b: bool, M: int, N: int, K: int, out: Tensor,
          bias: Optional[Tensor] = None, epilogue: int = L.EPI_STORE, res: Optional[Tensor] = None,
          gamma: Optional[Tensor] = None, row_idx: Optional[Tensor] = None, aux: Optional[Tensor] = None,

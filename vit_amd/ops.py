@@ -538,7 +538,11 @@ class AttentionSublayerFn(torch.autograd.Function):
         if table is not None and not fuse_rope:
             K.rope_qk_(dqkv, table, Bk, S, H, Dh, S - table.shape[-2], True, emu)
         dqn = [None, None, None, None]   # d q_norm.weight, d q_norm.bias, d k_norm.weight, d k_norm.bias
-        if qn_w is not None:
+        if qn_w is not None and K.can_qk_norm_bwd_inplace(dqkv, Dh) and pre_q.dtype == dqkv.dtype and qn_w.dtype == kn_w.dtype:
+            # per-head normalisation backward in place on the packed gradient: no head is copied out or back
+            dqn = list(K.qk_norm_bwd_(dqkv, pre_q, pre_k, rstd_q, rstd_k, mean_q, mean_k, qn_w.detach(), kn_w.detach(), H, Dh,
+                                      opt["qk_layernorm"], (need[10], has_qnb and need[11], need[12], has_knb and need[13])))
+        elif qn_w is not None:
             for which, (w_, pre, r_, m_, has_b) in enumerate(((qn_w, pre_q, rstd_q, mean_q, has_qnb),
                                                               (kn_w, pre_k, rstd_k, mean_k, has_knb))):
                 dpost = dqkv[:, which * D:(which + 1) * D].contiguous().view(M * H, Dh)

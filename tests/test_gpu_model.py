@@ -275,8 +275,17 @@ def oracle_cfg(cfg) -> "O.OracleConfig":
     return O.OracleConfig(**{k: v for k, v in cfg.__dict__.items()})
 
 
+def close_l2(a, b, rtol, name=""):
+    """Relative L2 distance: for stacks so deep that two equally valid bf16 computations drift apart element by element
+    (every residual add of a pure-bf16 stream rounds), the max-norm test of `close` no longer separates a wrong kernel from
+    rounding; the L2 distance still does."""
+    a, b = a.double().cpu(), b.double().cpu()
+    err = (a - b).norm().item() / max(b.norm().item(), 1e-30)
+    assert err <= rtol, f"{name}: relative L2 distance {err:.3e} > {rtol}"
+
+
 def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_mean", grad_rtol=None, state_seed=3,
-                               oracle_device="cpu", keep_ratio=None):
+                               oracle_device="cpu", keep_ratio=None, l2=False):
     """Same weights, same input: vit_amd (HIP kernels) vs the oracle's torch ops.  The oracle runs on the CPU unless
     the case draws random numbers on the device (drop-path's randperm); then it runs on the GPU with the same
     torch.manual_seed, with MIOpen and the fused SDPA backends switched off so it uses plain ATen math."""
@@ -307,10 +316,16 @@ def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_
         finally:
             torch.backends.cudnn.enabled = old
     assert out.dtype == ref["out"].dtype
-    close(out, ref["out"], rtol, "out")
     grtol = grad_rtol or rtol
-    close(xg, ref["x_grad"], grtol, "x_grad", atol_scale=2.0)
     assert set(grads) == set(ref["grads"])
+    if l2:
+        close_l2(out, ref["out"], rtol, "out")
+        close_l2(xg, ref["x_grad"], grtol, "x_grad")
+        for k, gr in ref["grads"].items():
+            close_l2(grads[k], gr, grtol, k)
+        return model
+    close(out, ref["out"], rtol, "out")
+    close(xg, ref["x_grad"], grtol, "x_grad", atol_scale=2.0)
     for k, gr in ref["grads"].items():
         close(grads[k], gr, grtol, k, atol_scale=2.0)
     return model
@@ -439,6 +454,84 @@ def test_bf16_gradient_copies_are_handed_from_block_to_block():
     assert stats_h["taken"] == stats["taken"] - 1, stats_h
     for k in grads:
         close(grads_h[k], grads[k], 1e-5, k)
+
+
+def test_vit_b14_full_depth_autocast_matches_oracle():
+    """BASELINE config 2 at its full depth (12 blocks, S = 272, D = 768, F = 3072), batch 8: outputs and every gradient
+    against the oracle's eager bf16-autocast arithmetic on the same device, at the bf16 tolerance."""
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(224, 224), depth=12, hidden_size=768, ffn_hidden_size=3072,
+                    num_attention_heads=12, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu",
+                    pos_enc="fourier", num_register_tokens=16, dtype=torch.float32)
+    compare_with_oracle_on_gpu(cfg, 8, (224, 224), True, 2e-2, grad_rtol=2e-2, oracle_device="cuda")
+
+
+def test_vit_l16_full_depth_bf16_matches_oracle():
+    """BASELINE config 3 at its full depth (24 blocks, S = 576, D = 1024, F = 4096, pure bf16, RoPE, SReLU), batch 2."""
+    cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(384, 384), depth=24, hidden_size=1024,
+                    ffn_hidden_size=4096, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
+                    activation="srelu", pos_enc="rope", dtype=torch.bfloat16)
+    compare_with_oracle_on_gpu(cfg, 2, (384, 384), False, 2e-2, grad_rtol=2e-2, oracle_device="cuda")
+
+
+def test_vit_h14_full_depth_droppath_ckpt_bf16_matches_oracle():
+    """BASELINE config 4 at its full depth (32 blocks, head_dim 80, drop-path 0.25 + layer scale + activation
+    checkpointing), batch 4; the oracle draws the same drop-path subsets from the same device generator."""
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(224, 224), depth=32, hidden_size=1280,
+                    ffn_hidden_size=5120, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
+                    activation="srelu", pos_enc="rope", drop_path_rate=0.25, layer_scale=1.0,
+                    activation_checkpointing=True, dtype=torch.bfloat16)
+    compare_with_oracle_on_gpu(cfg, 4, (224, 224), False, 2e-2, grad_rtol=2e-2, oracle_device="cuda")
+
+
+def test_vit_g14_1024px_four_blocks_bf16_matches_oracle():
+    """BASELINE config 5 (ViT-g/14 at 1024 px, S = 5329, head_dim 88) at depth 4, batch 1."""
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(1024, 1024), depth=4, hidden_size=1408,
+                    ffn_hidden_size=6144, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
+                    activation="swiglu", pos_enc="rope", dtype=torch.bfloat16)
+    compare_with_oracle_on_gpu(cfg, 1, (1024, 1024), False, 2e-2, grad_rtol=2e-2, oracle_device="cuda")
+
+
+def test_forty_block_bf16_stack_is_as_close_to_fp32_arithmetic_as_the_reference_arithmetic():
+    """ViT-g/14's 40 blocks in pure bf16 (224 px so that an fp32 run of the oracle fits): after 80 roundings of the bf16
+    residual stream two valid bf16 computations differ by more than 2 % in places (at 1024 px: relative L2 distance 3.3e-2
+    between this library and the oracle), so the yardstick here is exact arithmetic: the distance of this library's
+    output and gradients from the oracle run in fp32 on the same (bf16-valued) weights may not exceed the distance of the
+    oracle's own bf16 run from it by more than a quarter."""
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(224, 224), depth=40, hidden_size=1408,
+                    ffn_hidden_size=6144, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
+                    activation="swiglu", pos_enc="rope", dtype=torch.bfloat16)
+    model = cfg.instantiate(device=DEV)
+    sd = O.randomize_state(O.init_state(oracle_cfg(cfg), seed=3), seed=4)
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16).to(DEV)
+    out, xg, grads = run_train(model, x, False, 1234)
+    ocfg = oracle_cfg(cfg)
+    import dataclasses
+    ocfg32 = dataclasses.replace(ocfg, dtype=torch.float32)
+    old = torch.backends.cudnn.enabled
+    torch.backends.cudnn.enabled = False   # plain ATen convolution (MIOpen's search alone takes minutes here)
+    try:
+        with sdpa_kernel(SDPBackend.MATH):
+            ref16 = O.run_fwd_bwd(ocfg, {k: v.to(DEV) for k, v in sd.items()}, x, training=True, autocast=None, loss="square_mean",
+                                  seed=1234)
+            ref32 = O.run_fwd_bwd(ocfg32, {k: v.float().to(DEV) for k, v in sd.items()}, x.float(), training=True, autocast=None,
+                                  loss="square_mean", seed=1234)
+    finally:
+        torch.backends.cudnn.enabled = old
+
+    def dist(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+    report = {}
+    for name, mine, r16, r32 in [("out", out, ref16["out"], ref32["out"]), ("x_grad", xg, ref16["x_grad"], ref32["x_grad"])] + \
+            [(k, grads[k], ref16["grads"][k], ref32["grads"][k]) for k in ("blocks.0.mlp.fc1.weight", "blocks.20.self_attention.qkv_proj.weight",
+                                                                          "blocks.39.mlp.fc2.weight", "stem.patch.weight")]:
+        d_mine, d_ref = dist(mine, r32), dist(r16, r32)
+        report[name] = (d_mine, d_ref)
+        assert d_mine <= 1.25 * d_ref + 1e-3, f"{name}: this library {d_mine:.3e} from fp32, the reference's bf16 arithmetic {d_ref:.3e}"
+    print({k: (round(a, 4), round(b, 4)) for k, (a, b) in report.items()})
 
 
 def test_vit_l16_rope_srelu_bf16_matches_oracle():

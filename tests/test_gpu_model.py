@@ -1,7 +1,8 @@
 """GPU parity of the whole encoder (HIP kernels through the C ABI) against
   (1) the committed golden vectors produced by the live reference (tests/golden/*.pt), and
   (2) the oracle (torch-op restatement) run on the same seeded inputs.
-Tolerances (north-star): fp32 rtol 1e-4, bf16 / autocast rtol 2e-2; absolute floor = tolerance x max|expected|."""
+Tolerances (north-star): fp32 rtol 1e-4, bf16 / autocast rtol 2e-2; absolute floor = tolerance x max|expected| for outputs and
+gradients alike (twice that for the gradients of three pure-bf16 cases, each marked where it is set)."""
 import pytest
 import torch
 
@@ -82,11 +83,11 @@ def test_golden_fixture(name, algo):
         out, xg, grads = run_train(model, x, ac, fix["train_seed"], mask=mask)
         close(out, fix["train_out"], rtol, "train_out")
         grtol = rtol if mode == "fp32" else 2e-2
-        close(xg, fix["x_grad"], grtol, "x_grad", atol_scale=2.0)
+        close(xg, fix["x_grad"], grtol, "x_grad", atol_scale=1.0)
         assert set(grads) == set(fix["grads"])
         for k, g in fix["grads"].items():
             assert grads[k].dtype == g.dtype, k
-            close(grads[k], g, grtol, k, atol_scale=2.0)
+            close(grads[k], g, grtol, k, atol_scale=1.0)
     finally:
         K.set_algo(old)
 
@@ -115,12 +116,12 @@ def test_heads_golden_fixture(name):
         assert outs[k].dtype == v.dtype and outs[k].shape == v.shape, k
         close(outs[k].detach(), v, rtol, k)
     grtol = rtol if mode == "fp32" else 2e-2
-    close(xg.grad, fix["x_grad"], grtol, "x_grad", atol_scale=2.0)
+    close(xg.grad, fix["x_grad"], grtol, "x_grad", atol_scale=1.0)
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(grads) == set(fix["grads"])
     for k, g in fix["grads"].items():
         assert grads[k].dtype == g.dtype, k
-        close(grads[k], g, grtol, k, atol_scale=2.0)
+        close(grads[k], g, grtol, k, atol_scale=1.0)
     # attention probabilities: ViT.forward_attention_weights and AttentivePool.forward_weights
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "autocast_bf16"):
         w = model.forward_attention_weights(fix["x"].to(DEV))
@@ -156,12 +157,12 @@ def test_decoder_layers_golden_fixture(name, kind):
     assert out.dtype == part["out"].dtype
     close(out.detach(), part["out"], rtol, "out")
     grtol = rtol if mode == "fp32" else 2e-2
-    close(x.grad, part["x_grad"], grtol, "x_grad", atol_scale=2.0)
-    close(kv.grad, part["kv_grad"], grtol, "kv_grad", atol_scale=2.0)
+    close(x.grad, part["x_grad"], grtol, "x_grad", atol_scale=1.0)
+    close(kv.grad, part["kv_grad"], grtol, "kv_grad", atol_scale=1.0)
     grads = {k: p.grad for k, p in layer.named_parameters() if p.grad is not None}
     assert set(grads) == set(part["grads"])
     for k, g in part["grads"].items():
-        close(grads[k], g, grtol, k, atol_scale=2.0)
+        close(grads[k], g, grtol, k, atol_scale=1.0)
 
 
 def test_decoder_layer_drop_path_matches_oracle_fp32():
@@ -193,10 +194,10 @@ def test_decoder_layer_drop_path_matches_oracle_fp32():
         ref = O.decoder_layer(oracle_cfg(cfg), params, "", xr, kvr, True, self_attn=True)
     ref.square().mean().backward()
     close(out.detach(), ref.detach(), 1e-4, "out")
-    close(x.grad, xr.grad, 1e-4, "x_grad", atol_scale=2.0)
-    close(kv.grad, kvr.grad, 1e-4, "kv_grad", atol_scale=2.0)
+    close(x.grad, xr.grad, 1e-4, "x_grad", atol_scale=1.0)
+    close(kv.grad, kvr.grad, 1e-4, "kv_grad", atol_scale=1.0)
     for k, p in layer.named_parameters():
-        close(p.grad, params[k].grad, 1e-4, k, atol_scale=2.0)
+        close(p.grad, params[k].grad, 1e-4, k, atol_scale=1.0)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "autocast"])
@@ -240,10 +241,10 @@ def test_decoder_layer_with_rope_matches_oracle(mode, per_sample):
     rtol, grtol = (1e-4, 1e-4) if mode == "fp32" else (2e-2, 2e-2)
     assert out.dtype == ref.dtype
     close(out.detach(), ref.detach(), rtol, "out")
-    close(x.grad, xr.grad, grtol, "x_grad", atol_scale=2.0)
-    close(kv.grad, kvr.grad, grtol, "kv_grad", atol_scale=2.0)
+    close(x.grad, xr.grad, grtol, "x_grad", atol_scale=1.0)
+    close(kv.grad, kvr.grad, grtol, "kv_grad", atol_scale=1.0)
     for k, p in layer.named_parameters():
-        close(p.grad, params[k].grad, grtol, k, atol_scale=2.0)
+        close(p.grad, params[k].grad, grtol, k, atol_scale=1.0)
 
 
 def test_attentive_pool_head_trains_with_dropout():
@@ -285,7 +286,7 @@ def close_l2(a, b, rtol, name=""):
 
 
 def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_mean", grad_rtol=None, state_seed=3,
-                               oracle_device="cpu", keep_ratio=None, l2=False):
+                               oracle_device="cpu", keep_ratio=None, l2=False, grad_atol_scale=1.0):
     """Same weights, same input: vit_amd (HIP kernels) vs the oracle's torch ops.  The oracle runs on the CPU unless
     the case draws random numbers on the device (drop-path's randperm); then it runs on the GPU with the same
     torch.manual_seed, with MIOpen and the fused SDPA backends switched off so it uses plain ATen math."""
@@ -325,9 +326,9 @@ def compare_with_oracle_on_gpu(cfg, B, hw, autocast, rtol, seed=0, loss="square_
             close_l2(grads[k], gr, grtol, k)
         return model
     close(out, ref["out"], rtol, "out")
-    close(xg, ref["x_grad"], grtol, "x_grad", atol_scale=2.0)
+    close(xg, ref["x_grad"], grtol, "x_grad", atol_scale=grad_atol_scale)
     for k, gr in ref["grads"].items():
-        close(grads[k], gr, grtol, k, atol_scale=2.0)
+        close(grads[k], gr, grtol, k, atol_scale=grad_atol_scale)
     return model
 
 
@@ -367,9 +368,9 @@ def test_ragged_mask_pads_short_samples_fp32():
         ref = O.run_fwd_bwd(oracle_cfg(cfg), sd, x, training=True, seed=1, mask=mask)
         assert out.shape == ref["out"].shape == (3, 25, 64)
         close(out, ref["out"], 1e-4, "out")
-        close(xg, ref["x_grad"], 1e-4, "x_grad", atol_scale=2.0)
+        close(xg, ref["x_grad"], 1e-4, "x_grad", atol_scale=1.0)
         for k, gr in ref["grads"].items():
-            close(grads[k], gr, 1e-4, k, atol_scale=2.0)
+            close(grads[k], gr, 1e-4, k, atol_scale=1.0)
 
 
 @pytest.mark.parametrize("mode", ["autocast", "bf16"])
@@ -389,7 +390,9 @@ def test_qk_normalization_matches_oracle(mode, norm_type):
                     qk_normalization=True, norm_type=norm_type, num_register_tokens=2,
                     dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
     rtol = 1e-4 if mode == "fp32" else 2e-2
-    compare_with_oracle_on_gpu(cfg, 3, (32, 48), mode == "autocast", rtol, grad_rtol=None if mode == "fp32" else 2e-2)
+    # pure bf16: the input gradient is a bf16 tensor of magnitude 1e-4 whose last-place steps are wider than 2 % of most elements
+    compare_with_oracle_on_gpu(cfg, 3, (32, 48), mode == "autocast", rtol, grad_rtol=None if mode == "fp32" else 2e-2,
+                               grad_atol_scale=2.0 if mode == "bf16" else 1.0)
 
 
 def test_activation_checkpointing_equals_plain_fp32():
@@ -470,7 +473,8 @@ def test_vit_l16_full_depth_bf16_matches_oracle():
     cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(384, 384), depth=24, hidden_size=1024,
                     ffn_hidden_size=4096, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
                     activation="srelu", pos_enc="rope", dtype=torch.bfloat16)
-    compare_with_oracle_on_gpu(cfg, 2, (384, 384), False, 2e-2, grad_rtol=2e-2, oracle_device="cuda")
+    # 24 pure-bf16 blocks: a few gradient elements of two valid bf16 computations are further apart than 2 % of the maximum
+    compare_with_oracle_on_gpu(cfg, 2, (384, 384), False, 2e-2, grad_rtol=2e-2, oracle_device="cuda", grad_atol_scale=2.0)
 
 
 def test_vit_h14_full_depth_droppath_ckpt_bf16_matches_oracle():
@@ -480,7 +484,7 @@ def test_vit_h14_full_depth_droppath_ckpt_bf16_matches_oracle():
                     ffn_hidden_size=5120, num_attention_heads=16, hidden_dropout=0.0, attention_dropout=0.0,
                     activation="srelu", pos_enc="rope", drop_path_rate=0.25, layer_scale=1.0,
                     activation_checkpointing=True, dtype=torch.bfloat16)
-    compare_with_oracle_on_gpu(cfg, 4, (224, 224), False, 2e-2, grad_rtol=2e-2, oracle_device="cuda")
+    compare_with_oracle_on_gpu(cfg, 4, (224, 224), False, 2e-2, grad_rtol=2e-2, oracle_device="cuda", grad_atol_scale=2.0)   # 32 bf16 blocks
 
 
 def test_vit_g14_1024px_four_blocks_bf16_matches_oracle():
@@ -572,7 +576,7 @@ def test_vit_s16_fp32_forward_config1():
     with torch.inference_mode():
         out = model(x.to(DEV)).dense_features
         ref = O.vit_forward(oracle_cfg(cfg), sd, x, training=False)
-    close(out, ref, 1e-4, atol_scale=2.0)
+    close(out, ref, 1e-4, atol_scale=1.0)
 
 
 def test_dropout_training_is_stochastic_and_eval_is_deterministic():

@@ -538,6 +538,42 @@ def test_forty_block_bf16_stack_is_as_close_to_fp32_arithmetic_as_the_reference_
     print({k: (round(a, 4), round(b, 4)) for k, (a, b) in report.items()})
 
 
+def test_training_step_captures_into_a_hip_graph_and_replays_bit_identically():
+    """Nothing on the path synchronises with the host or allocates outside torch's capturable allocator: forward + backward
+    of an encoder (autocast, SwiGLU, RoPE fused in the projection, split-K weight gradients) records into one
+    torch.cuda.CUDAGraph, and a replay on new input values gives the gradients of the eager step on those values."""
+    cfg = ViTConfig(in_channels=3, patch_size=(14, 14), img_size=(112, 112), depth=2, hidden_size=256, ffn_hidden_size=512,
+                    num_attention_heads=4, hidden_dropout=0.0, attention_dropout=0.0, activation="swiglu", pos_enc="rope",
+                    num_register_tokens=4, dtype=torch.float32)
+    model = cfg.instantiate(device=DEV).train()
+    x = torch.randn(16, 3, 112, 112, device=DEV)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            model(x).dense_features.float().square().mean().backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+            model.zero_grad(set_to_none=True)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    x.copy_(torch.randn(16, 3, 112, 112, device=DEV))   # new values in the captured input buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    step()
+    want = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(want) and len(got) > 10
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
 def test_vit_l16_rope_srelu_bf16_matches_oracle():
     """BASELINE config 3 at depth 2: pure bf16 parameters, RoPE, SReLU, S = 576."""
     cfg = ViTConfig(in_channels=3, patch_size=(16, 16), img_size=(384, 384), depth=2, hidden_size=1024,

@@ -73,9 +73,10 @@ def test_gemm_fused_bias_gradient_row_sums(shape):
 
 @pytest.mark.parametrize("Kd", [192, 2304])
 def test_gemm_ragged_last_round_is_cut_between_tile_sizes(Kd):
-    """270 tiles of 256x256 on 256 CUs: the automatic path runs whole rounds on the 256-tile kernel and the remaining
-    rows on the 128-tile kernel (with a long contraction those few tiles are split along K and the residual epilogue
-    is applied by the pass that sums the partial products).  Integer operands make every kernel exact, so the cut must
+    """270 tiles of 256x256 on 256 CUs: with the long contraction the automatic path runs whole rounds on the 256-tile
+    kernel and the remaining rows on the 128-tile kernel (those few tiles are split along K and the residual epilogue
+    is applied by the pass that sums the partial products); with the short one a second round costs less than a
+    second launch and the problem stays whole.  Integer operands make every kernel exact, so the cut must
     be invisible; the residual epilogue is checked with a row gather and dropout (same mask as the uncut launch)."""
     M, N = 256 * 90, 768
     g = torch.Generator().manual_seed(11)

@@ -889,6 +889,14 @@ static int64_t ragged_round_cut(const VitkGemm* g) {
   if (rounds < 1 || rem == 0 || rem * 10 > cus * 6) return 0;     // a last round that is over 60% full stays
   const int64_t tm_main = rounds * cus / tn;
   if (tm_main < 1 || tm_main >= tm) return 0;
+  // The cut trades the last round of the large kernel (one tile time, whatever its fill) for a launch of the small kernel
+  // over the rows behind the cut.  Measured on MI355X, in microseconds: a 256^2 tile takes 1.3 per K-step + 5 (+ 8 with
+  // the residual epilogue); the small kernel 12 + its FLOPs at 0.9 PFLOP/s (+ 9 for the reduction of a split contraction).
+  // Short contractions (K = 768: a 21 us tile against a 26-30 us launch) are therefore left whole.
+  const double t_tile = (double)ceil_div(g->K, BK) * 1.3 + 5.0 + (g->epilogue == VITK_EPI_RESIDUAL ? 8.0 : 0.0);
+  const double rows_left = (double)(g->M - tm_main * BM2);
+  const double t_left = 12.0 + 2.0 * rows_left * (double)g->N * (double)g->K / 0.9e9 + (g->K >= 2048 ? 9.0 : 0.0);
+  if (t_left > 0.9 * t_tile) return 0;
   return tm_main * BM2;
 }
 

@@ -1,4 +1,5 @@
-"""Attention micro-benchmark (forward, backward) on the encoder's shapes through the C ABI."""
+"""Attention micro-benchmark (forward, backward) on the encoder's shapes through the C ABI.
+python tools/bench_attn.py [B S H Dh]      (DROP=0.1 in the environment: with dropout on the probabilities)"""
 import os
 import sys
 
@@ -25,8 +26,9 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-o, lse = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5)
-f = timeit(lambda: K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5))
-b = timeit(lambda: K.attn_bwd(qkv, o, lse, dout, B, S, H, Dh, Dh ** -0.5))
+DROP = float(os.environ.get("DROP", "0"))
+o, lse = K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, DROP, 1234)
+f = timeit(lambda: K.attn_fwd(qkv, B, S, H, Dh, Dh ** -0.5, DROP, 1234))
+b = timeit(lambda: K.attn_bwd(qkv, o, lse, dout, B, S, H, Dh, Dh ** -0.5, DROP, 1234))
 fl = 4.0 * B * H * S * S * Dh
-print(f"B={B} S={S} H={H} Dh={Dh}: fwd {f:.3f} ms ({fl / f / 1e9:.0f} TF/s)  bwd {b:.3f} ms ({2.5 * fl / b / 1e9:.0f} TF/s algorithmic)")
+print(f"B={B} S={S} H={H} Dh={Dh} drop={DROP}: fwd {f:.3f} ms ({fl / f / 1e9:.0f} TF/s)  bwd {b:.3f} ms ({2.5 * fl / b / 1e9:.0f} TF/s algorithmic)")

@@ -34,9 +34,27 @@ struct AttnP {
 };
 
 #define LOG2E 1.4426950408889634f
+// waves per SIMD the dropout instances (head_dim <= 64, 4-wave workgroups) are compiled for; measured at S = 272, B = 256:
+// forward 0.263 ms at 2 and 0.218 at 3 (one spilled register); dQ is slower at 3 (16 spilled registers); dK/dV fits two
+// (251 registers, no spill) since its draws come from 32-bit terms: backward 0.77 ms at 1, 0.62 at 2
+#ifndef DROP_OCC_FWD
+#define DROP_OCC_FWD 3
+#endif
+#ifndef DROP_OCC_DQ
+#define DROP_OCC_DQ 2
+#endif
+#ifndef DROP_OCC_DKDV
+#define DROP_OCC_DKDV 2
+#endif
+#define drop_xrow(p, row, lane) drop_xrow_raw((p).seed, drop_ld((p).Sk), (row), (lane))
 // Dropout counter of probability (query row, key): row * drop_ld(Sk) + key, with the row stride rounded up to even so
 // that keys 2i and 2i + 1 of every row share one hash (rng_pair)
 __device__ __forceinline__ uint64_t drop_ld(int64_t Sk) { return (uint64_t)((Sk + 1) & ~(int64_t)1); }
+// Hash input (rng_lin_run) of the pair that holds (row, key = 4 * (lane >> 5)): the MFMA tiles put keys k and k + 4 on the
+// two halves of a wave, so the half's offset is folded into the per-lane term once.
+__device__ __forceinline__ uint32_t drop_xrow_raw(uint64_t seed, uint64_t ld, uint64_t row, int lane) {
+  return (uint32_t)(row * (ld >> 1)) * RNG_C1 + (uint32_t)(2 * (lane >> 5)) * RNG_C1 + rng_seedmix(seed);
+}
 
 // delta[b,h,s] = sum_d dO * O   (one wave per row)
 template <class T>
@@ -546,7 +564,7 @@ static unsigned head_block_grid(int64_t B, int64_t H, int64_t S, int rows_per_bl
 template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS, int KW = 0, int VW = 0>
 __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const char* sV, const bf16x8 (&qf)[DHP / 16],
                                          f32x16 (&oacc)[DHP / 32], f32x16& lacc, float& m, float c, int k0, int S,
-                                         uint64_t rbase, int lane) {
+                                         uint32_t xrow, int lane) {
   const f32x16 zero = ZERO16;
   const int rowoff = 4 * (lane >> 5);
   f32x16 sacc[HALVES];
@@ -597,8 +615,8 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
       if (DROP) {   // registers 8 s2 + 0..3 and + 4..7 are two runs of four consecutive keys, each from a multiple of 4
 #pragma unroll
         for (int g = 0; g < 2; g++) {
-          uint32_t dr[4];
-          rng_run<4>(p.seed, rbase + (uint64_t)(k0 + st * 32 + acc_row(8 * s2 + 4 * g) + rowoff), dr);
+          uint32_t dr[4];   // keys k0 + st*32 + acc_row(.) + rowoff ..: xrow already holds the row and rowoff / 2
+          rng_lin_run<4>(xrow + (uint32_t)((k0 + st * 32 + acc_row(8 * s2 + 4 * g)) >> 1) * RNG_C1, dr);
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int r = 8 * s2 + 4 * g + j;
@@ -614,7 +632,7 @@ __device__ __forceinline__ void fwd_tile(const AttnP& p, const char* sK, const c
 }
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && NW == 4 && (!DROP || DROP_OCC_FWD == 3)) ? 3 : DHP <= 96 ? 2 : 1)) void attn_fwd_k(AttnP p) {
 #ifdef EXP_STAMP   // diagnostic build: cycle stamps of wave 0 per block go to the lse buffer (tools/stamp_attn.py reads them)
   const uint64_t st0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -650,7 +668,8 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
   for (int dt = 0; dt < DHP / 32; dt++) oacc[dt] = zero;
   float m = -INFINITY;
   const float c = p.scale * LOG2E;
-  const uint64_t rbase = ((uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow) * drop_ld(p.Sk);
+  // hash input of (this lane's query row, key pair rowoff / 2): row * (ld / 2) * C1 + (rowoff / 2) * C1 + mix(seed)
+  const uint32_t rbase = drop_xrow(p, (uint64_t)(b * p.H + h) * p.S + (uint64_t)qrow, lane);
   stage_store<DHP, NT, NCH, KS, false>(rkA, smem, tid);
   stage_store<DHP, NT, NCH, VS, false>(rvA, smem + 64 * KS, tid);
   __syncthreads();
@@ -708,7 +727,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
 template <int DHP, int HALVES, bool PARTIAL, bool DROP, int KS, int VS, int KW = 1, int VW = 0>
 __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const char* sV, const bf16x8 (&qf)[DHP / 16],
                                         const bf16x8 (&gf)[DHP / 16], f32x16 (&dqacc)[DHP / 32], float nlse2, float delta,
-                                        float c, int k0, int S, uint64_t rbase, int lane) {
+                                        float c, int k0, int S, uint32_t xrow, int lane) {
   const f32x16 zero = ZERO16;
   const int rowoff = 4 * (lane >> 5);
 #pragma unroll
@@ -724,7 +743,7 @@ __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const ch
 #pragma unroll
     for (int g = 0; g < 4; g++) {   // registers 4 g .. 4 g + 3: four consecutive keys from a multiple of 4
       uint32_t dr[4] = {0u, 0u, 0u, 0u};
-      if (DROP) rng_run<4>(p.seed, rbase + (uint64_t)(k0 + st * 32 + acc_row(4 * g) + rowoff), dr);
+      if (DROP) rng_lin_run<4>(xrow + (uint32_t)((k0 + st * 32 + acc_row(4 * g)) >> 1) * RNG_C1, dr);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int r = 4 * g + j;
@@ -747,7 +766,7 @@ __device__ __forceinline__ void dq_tile(const AttnP& p, const char* sK, const ch
 }
 
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, ((DHP <= 64 && NW == 4 && (!DROP || DROP_OCC_DQ == 3)) ? 3 : DHP <= 96 ? 2 : 1)) void attn_dq_k(AttnP p) {
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int KS = Strides<DHP>::COLS, VS = Strides<DHP>::ROWS;  // K is read both ways (swizzled), V row-wise only
   constexpr int TILE = 64 * KS + 64 * VS;
@@ -791,7 +810,7 @@ __global__ __launch_bounds__(NW * 64, ((DHP <= 64 && !DROP && NW == 4) ? 3 : DHP
     if (qv && lane < 32) p.delta[srow] = delta;
   }
   const float c = p.scale * LOG2E;
-  const uint64_t rbase = (uint64_t)srow * drop_ld(p.Sk);
+  const uint32_t rbase = drop_xrow(p, (uint64_t)srow, lane);
   const f32x16 zero = ZERO16;
   f32x16 dqacc[DHP / 32];
 #pragma unroll
@@ -851,6 +870,12 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
   const f32x16 zero = ZERO16;
   const int rowoff = 4 * (lane >> 5);
   constexpr bool INIT = dkdv_init_consts<DHP, DROP>();
+  // dropout draws: element (query, key) is pair query * (ld / 2) + key / 2, half key & 1
+  const uint32_t xstep = (uint32_t)(drop_ld(p.Sk) >> 1) * RNG_C1;
+  const bool kodd = krow & 1;
+  const uint32_t xkey = (uint32_t)((uint64_t)(sbase + q0 + rowoff + (kodd ? 1 : 0)) * (drop_ld(p.Sk) >> 1)) * RNG_C1 +
+                        (uint32_t)(krow >> 1) * RNG_C1 + rng_seedmix(p.seed);
+  const int khalf = kodd ? 0 : 16;
 #pragma unroll
   for (int st = 0; st < HALVES; st++) {
     // sacc[r] = S[q = q0 + st*32 + row(r)][key = lane&31], pacc likewise for dP
@@ -885,13 +910,27 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
         const int ql = st * 32 + 8 * g + rowoff;
         const f32x4 l4 = *(const f32x4*)(sL + ql);
         const f32x4 d4 = *(const f32x4*)(sL + 64 + ql);
+        uint32_t drops[4] = {0u, 0u, 0u, 0u};
+        if (DROP) {
+          // The lanes of keys 2i and 2i + 1 draw from the same hash of (query row, key pair i): the even lane computes the
+          // hashes of this group's rows 0 and 2, the odd lane those of rows 1 and 3, and a neighbour swap hands each lane
+          // the other two.  xkey holds the lane's own first row already (its parity folded in).
+#pragma unroll
+          for (int jj = 0; jj < 2; jj++) {
+            const uint32_t mine = rng_fmix(xkey + (uint32_t)(st * 32 + 8 * g + 2 * jj) * xstep);
+            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            const uint32_t h0 = kodd ? other : mine, h1 = kodd ? mine : other;   // hashes of rows 2 jj and 2 jj + 1
+            drops[2 * jj] = (h0 << khalf) & 0xffff0000u;
+            drops[2 * jj + 1] = (h1 << khalf) & 0xffff0000u;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int r = 4 * g + j;
           const float pr = fast_exp2(fmaf(sacc[r], c, l4[j]));
           float pd = pr, dp = pacc[r];
           if (DROP) {
-            const bool keep = rng_u32(p.seed, (uint64_t)(sbase + q0 + ql + j) * drop_ld(p.Sk) + (uint64_t)krow) >= p.thr;
+            const bool keep = drops[j] >= p.thr;
             pd = keep ? pr * p.keep_scale : 0.f;
             dp = keep ? dp * p.keep_scale : 0.f;
           }
@@ -919,7 +958,7 @@ __device__ __forceinline__ void dkdv_tile(const AttnP& p, const char* sQ, const 
 template <int DHP, int NW, bool DROP>
 constexpr int dkdv_ahead() { return (DHP > 64 && DHP <= 96 && !DROP && NW == 4) ? 1 : 2; }
 template <int DHP, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, (((DHP <= 64 || (DHP <= 96 && NW == 4)) && !DROP) ? 2 : 1)) void attn_dkdv_k(AttnP p) {
+__global__ __launch_bounds__(NW * 64, (((DHP <= 64 && (!DROP || (DROP_OCC_DKDV == 2 && NW == 4))) || (DHP <= 96 && NW == 4 && !DROP)) ? 2 : 1)) void attn_dkdv_k(AttnP p) {
   constexpr int AHEAD = dkdv_ahead<DHP, NW, DROP>();
   constexpr int NT = NW * 64, CPR = DHP / 8, NCH = (64 * CPR + NT - 1) / NT;
   constexpr int QS = Strides<DHP>::COLS;   // Q and dO tiles are read both ways (swizzled)

@@ -113,22 +113,40 @@ __device__ __forceinline__ float wave_max(float v) {
 // high half, each as the top 16 bits of the draw that is compared with the threshold p * 2^32 (the keep probability is
 // then exact to 2^-16).  An element costs half a hash that way, and the integer multiplies of the hash are what a
 // dropout epilogue is made of (they issue at a quarter of the vector rate).
-__device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair) {
-  const uint32_t lo = (uint32_t)pair ^ (uint32_t)seed;
-  const uint32_t hi = (uint32_t)(pair >> 32) ^ (uint32_t)(seed >> 32);
-  uint32_t x = lo * 0x9E3779B1u + hi * 0x85EBCA77u + 0x165667B1u;
+// The hash input is LINEAR in the pair number, x = pair * RNG_C1 + mix(seed) in 32-bit arithmetic, so a kernel that walks
+// a 2-D index space (row * stride + column) forms it from a per-row and a per-column term with one add per draw
+// (rng_lin_*), with no 64-bit arithmetic and no multiply in front of the finaliser; pair numbers 2^32 apart share draws.
+constexpr uint32_t RNG_C1 = 0x9E3779B1u;
+__device__ __forceinline__ uint32_t rng_seedmix(uint64_t seed) {   // wave-uniform: scalar code
+  return (uint32_t)seed * 0x85EBCA77u + (uint32_t)(seed >> 32) * 0xC2B2AE3Du + 0x165667B1u;
+}
+__device__ __forceinline__ uint32_t rng_fmix(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
+}
+__device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair) {
+  return rng_fmix((uint32_t)pair * RNG_C1 + rng_seedmix(seed));
 }
 __device__ __forceinline__ uint32_t rng_half(uint32_t h, int odd) { return odd ? (h & 0xffff0000u) : (h << 16); }
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) { return rng_half(rng_pair(seed, idx >> 1), (int)(idx & 1)); }
 // draws of the N consecutive elements base .. base + N - 1, base EVEN and N even: N / 2 hashes
 template <int N>
 __device__ __forceinline__ void rng_run(uint64_t seed, uint64_t base, uint32_t (&r)[N]) {
-  const uint64_t pair0 = base >> 1;
+  const uint32_t x0 = (uint32_t)(base >> 1) * RNG_C1 + rng_seedmix(seed);
 #pragma unroll
   for (int j = 0; j < N; j += 2) {
-    const uint32_t h = rng_pair(seed, pair0 + (uint64_t)(j >> 1));
+    const uint32_t h = rng_fmix(x0 + (uint32_t)(j >> 1) * RNG_C1);
+    r[j] = h << 16;
+    r[j + 1] = h & 0xffff0000u;
+  }
+}
+// The same draws from a precomputed hash input: x = (hash input of the pair that holds the first element); elements
+// first .. first + N - 1 with `first` even.
+template <int N>
+__device__ __forceinline__ void rng_lin_run(uint32_t x, uint32_t (&r)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const uint32_t h = rng_fmix(x + (uint32_t)(j >> 1) * RNG_C1);
     r[j] = h << 16;
     r[j + 1] = h & 0xffff0000u;
   }

@@ -266,6 +266,14 @@ int vitk_colsum_static(const void* a, int a_dtype, int64_t lda, const int64_t* a
 int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, void* out,
                     int out_dtype, int64_t rows, int64_t N, float alpha, float drop_p, uint64_t seed, void* stream);
 
+/* The same, with the gradient of the layer scale (vit/layer_scale.py:8-13) from the same pass over g:
+ * dgamma[n] = alpha * sum_r g[row(r), n] * aux[r, n], aux [rows, N] = the branch output the scale multiplied (what the
+ * residual epilogue of vitk_gemm saves), dgamma in the dtype of g / gamma.  N a multiple of 4, at most 4096. */
+size_t vitk_scale_cast_dgamma_workspace_bytes(int64_t N);
+int vitk_scale_cast_dgamma(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma, const void* aux,
+                           int aux_dtype, void* out, int out_dtype, void* dgamma, int64_t rows, int64_t N, float alpha,
+                           float drop_p, uint64_t seed, void* workspace, void* stream);
+
 /* ---- prefix tokens (vit/vit.py:500-505: torch.cat([cls_tokens.expand(B), register_tokens.expand(B), x], dim=1)) ----
  * out is the [B, S, D] sequence whose rows ncls + nreg .. S - 1 the patch-embedding GEMM writes (VITK_EPI_PATCH with
  * seq = S, prefix = ncls + nreg); this call fills rows 0 .. ncls + nreg - 1 of every sample with the learned tokens

@@ -461,6 +461,29 @@ def test_gemm_rope_epilogue_equals_projection_then_rotation(shape, algo, emu):
     assert not torch.equal(got, plain)
 
 
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("case", [(3000, 768, "float32", 0.0), (517, 1280, "bfloat16", 0.0), (64, 4096, "float32", 0.1), (1, 8, "float32", 0.25),
+                                  (2300, 1408, "float32", 0.1)])
+def test_scale_cast_with_layer_scale_gradient_equals_the_two_passes(case, gather):
+    """vitk_scale_cast_dgamma: the scaled / masked / cast branch gradient is bit-equal to vitk_scale_cast's, and the layer-scale
+    gradient equals vitk_colsum of g * aux (fp64 reference for the sum), with and without a row gather."""
+    rows, N, dtype, p = case
+    dt = getattr(torch, dtype)
+    gen = torch.Generator().manual_seed(rows + N)
+    src_rows = rows + 37 if gather else rows
+    g = torch.randn(src_rows, N, generator=gen).to(dt).to(DEV)
+    aux = torch.randn(rows, N, generator=gen).to(torch.bfloat16).to(DEV)
+    gamma = (0.1 + torch.rand(N, generator=gen)).to(dt).to(DEV)
+    idx = torch.randperm(src_rows, generator=gen)[:rows].to(DEV) if gather else None
+    want = K.scale_cast(g, rows, N, torch.bfloat16, row_idx=idx, gamma=gamma, alpha=0.5, drop_p=p, seed=77)
+    got, dgamma = K.scale_cast_dgamma(g, aux, rows, N, torch.bfloat16, gamma, row_idx=idx, alpha=0.5, drop_p=p, seed=77)
+    assert torch.equal(got, want)
+    picked = g if idx is None else g[idx]
+    ref = 0.5 * (picked.double() * aux.double()).sum(0)
+    assert dgamma.dtype == dt
+    close(dgamma.double(), ref, 1e-5 if dt == torch.float32 else 1e-2)
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 @pytest.mark.parametrize("layernorm", [False, True])
 @pytest.mark.parametrize("shape", [(37, 3, 64), (5, 2, 80), (130, 4, 88), (1, 1, 128), (600, 12, 64)])

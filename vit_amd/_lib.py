@@ -20,6 +20,7 @@ EXPORTS = [
     "vitk_qk_norm_bwd", "vitk_qk_norm_bwd_workspace_bytes",
     "vitk_gemm", "vitk_gemm_workspace_bytes", "vitk_attn_fwd", "vitk_attn_bwd", "vitk_attn_weights", "vitk_rope_qk", "vitk_rope_rows", "vitk_debug_hold_cus", "vitk_act_fwd",
     "vitk_act_bwd", "vitk_im2col", "vitk_col2im", "vitk_colsum", "vitk_colsum_static", "vitk_colsum_workspace_bytes", "vitk_scale_cast",
+    "vitk_scale_cast_dgamma", "vitk_scale_cast_dgamma_workspace_bytes",
     "vitk_prefix_fill", "vitk_copy_samples", "vitk_fourier_features", "vitk_fourier_features_bwd",
 ]
 
@@ -77,7 +78,8 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.vitk_last_error.restype = C.c_char_p
     lib.vitk_version.restype = C.c_int
-    for name in ("vitk_norm_bwd_workspace_bytes", "vitk_colsum_workspace_bytes", "vitk_qk_norm_bwd_workspace_bytes"):
+    for name in ("vitk_norm_bwd_workspace_bytes", "vitk_colsum_workspace_bytes", "vitk_qk_norm_bwd_workspace_bytes",
+                 "vitk_scale_cast_dgamma_workspace_bytes"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_int64]
     lib.vitk_gemm_workspace_bytes.restype = C.c_size_t
@@ -101,6 +103,7 @@ def load() -> C.CDLL:
         "vitk_colsum": [vp, i32, i64, vp, vp, i32, i64, vp, i32, i64, i64, f32, vp, vp],
         "vitk_colsum_static": [vp, i32, i64, vp, vp, i32, i64, vp, i32, i64, i64, f32, vp],
         "vitk_scale_cast": [vp, i32, i64, vp, vp, vp, i32, i64, i64, f32, f32, u64, vp],
+        "vitk_scale_cast_dgamma": [vp, i32, i64, vp, vp, vp, i32, vp, i32, vp, i64, i64, f32, f32, u64, vp, vp],
         "vitk_prefix_fill": [vp, i64, vp, i64, i32, vp, i32, i64, i64, i64, vp],
         "vitk_copy_samples": [vp, vp, vp, i64, i64, vp],
         "vitk_fourier_features": [vp, vp, vp, i32, i64, i64, i64, vp],

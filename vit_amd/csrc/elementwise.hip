@@ -1076,6 +1076,102 @@ extern "C" int vitk_scale_cast(const void* g, int g_dtype, int64_t ldg, const in
   return 0;
 }
 
+// The same pass with the layer-scale gradient taken on the way: dgamma[n] = alpha * sum_r g[row(r), n] * aux[r, n]
+// (aux = the branch output before the scale, as the residual epilogue saved it), so the gradient rows are read once for
+// both results.  A workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ...; thread t owns the 4-column groups t,
+// t + 256, ... of every row, keeps their partial sums in registers and leaves them in partial[block][N]; the partials
+// are folded like those of the norm backward.
+constexpr int SCD_BLOCKS = 1024, SCD_FOLD = 16;
+template <class TG, class TO, class TB, int MAXG>
+__global__ __launch_bounds__(256) void scale_cast_dgamma_k(const TG* __restrict__ g, int64_t ldg, const int64_t* __restrict__ row_idx,
+                                                           const TG* __restrict__ gamma, const TB* __restrict__ aux,
+                                                           TO* __restrict__ out, int64_t rows, int N, float alpha, uint32_t thr,
+                                                           float keep_scale, uint64_t seed, float* __restrict__ partial) {
+  float gm[MAXG][4], acc[MAXG][4];
+#pragma unroll
+  for (int k = 0; k < MAXG; k++) {
+    const int c = (threadIdx.x + k * 256) * 4;
+    Vec4<TG> t;
+    if (c < N) t.load(gamma + c);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { gm[k][i] = c < N ? t.v[i] * alpha : 0.f; acc[k][i] = 0.f; }
+  }
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int64_t src = row_idx ? row_idx[r] : r;
+#pragma unroll
+    for (int k = 0; k < MAXG; k++) {
+      const int c = (threadIdx.x + k * 256) * 4;
+      if (c < N) {
+        Vec4<TG> v; v.load(g + src * ldg + c);
+        Vec4<TB> a; a.load(aux + r * (int64_t)N + c);
+        Vec4<TO> o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { acc[k][i] += v.v[i] * a.v[i]; o.v[i] = v.v[i] * gm[k][i]; }
+        if (thr) {
+          uint32_t dr[4];
+          rng_run<4>(seed, (uint64_t)(r * N + c), dr);
+#pragma unroll
+          for (int i = 0; i < 4; i++) o.v[i] = dr[i] >= thr ? o.v[i] * keep_scale : 0.f;
+        }
+        o.store(out + r * (int64_t)N + c);
+      }
+    }
+  }
+  float* prow = partial + (size_t)blockIdx.x * N;
+#pragma unroll
+  for (int k = 0; k < MAXG; k++) {
+    const int c = (threadIdx.x + k * 256) * 4;
+    if (c < N) *(float4*)(prow + c) = make_float4(acc[k][0] * alpha, acc[k][1] * alpha, acc[k][2] * alpha, acc[k][3] * alpha);
+  }
+}
+
+extern "C" size_t vitk_scale_cast_dgamma_workspace_bytes(int64_t N) { return (size_t)(SCD_BLOCKS + SCD_FOLD) * (size_t)N * sizeof(float); }
+
+extern "C" int vitk_scale_cast_dgamma(const void* g, int g_dtype, int64_t ldg, const int64_t* row_idx, const void* gamma,
+                                      const void* aux, int aux_dtype, void* out, int out_dtype, void* dgamma, int64_t rows,
+                                      int64_t N, float alpha, float drop_p, uint64_t seed, void* workspace, void* stream) {
+  VITK_REQUIRE(g && out && gamma && aux && dgamma && workspace, "scale_cast_dgamma: null pointer");
+  VITK_REQUIRE(N > 0 && N % 4 == 0 && ldg % 4 == 0 && N <= 4096, "scale_cast_dgamma: N=%lld, ldg=%lld must be multiples of 4, N at most 4096",
+               (long long)N, (long long)ldg);
+  VITK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "scale_cast_dgamma: dropout p=%f out of range", drop_p);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t gbytes = (size_t)N * (g_dtype == VITK_F32 ? 4 : 2);
+  if (rows == 0) { (void)hipMemsetAsync(dgamma, 0, gbytes, st); return 0; }
+  const uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0;
+  const float ks = 1.f / (1.f - drop_p);
+  const int grid = (int)std::min<int64_t>(rows, SCD_BLOCKS);
+  float* ws = (float*)workspace;
+#define SCD_LAUNCH(MAXG)                                                                                                   \
+  hipLaunchKernelGGL((scale_cast_dgamma_k<TG, TO, TB, MAXG>), dim3(grid), dim3(256), 0, st, (const TG*)g, ldg, row_idx,    \
+                     (const TG*)gamma, (const TB*)aux, (TO*)out, rows, (int)N, alpha, thr, ks, seed, ws)
+  DISPATCH_DTYPE(g_dtype, TG, {
+    DISPATCH_DTYPE(out_dtype, TO, {
+      DISPATCH_DTYPE(aux_dtype, TB, {
+        if (N <= 1024) SCD_LAUNCH(1);
+        else if (N <= 2048) SCD_LAUNCH(2);
+        else SCD_LAUNCH(4);
+      });
+    });
+  });
+#undef SCD_LAUNCH
+  VITK_LAUNCH_CHECK("scale_cast_dgamma");
+  // fold [grid][N] -> [SCD_FOLD][N] -> [N] (dtype of gamma)
+  const float* src = ws;
+  int64_t src_rows = grid;
+  if (grid > 4 * SCD_FOLD) {
+    float* ws2 = ws + (size_t)SCD_BLOCKS * N;
+    dim3 g1((unsigned)ceil_div(N, 256), (unsigned)SCD_FOLD);
+    colsum_one<float, float, float>(true, g1, st, src, N, nullptr, (const float*)nullptr, 0, ws2, N, src_rows, N, 1.f);
+    src = ws2;
+    src_rows = SCD_FOLD;
+  }
+  dim3 g2((unsigned)ceil_div(N, 256), 1);
+  if (g_dtype == VITK_F32) colsum_one<float, float, float>(true, g2, st, src, N, nullptr, (const float*)nullptr, 0, (float*)dgamma, N, src_rows, N, 1.f);
+  else colsum_one<float, float, bf16>(true, g2, st, src, N, nullptr, (const float*)nullptr, 0, (bf16*)dgamma, N, src_rows, N, 1.f);
+  VITK_LAUNCH_CHECK("scale_cast_dgamma reduce");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // prefix tokens (vit/vit.py:500-505: cat([cls, register, patches], dim=1) with the learned tokens expanded over the
 // batch): out[b, r, :] = cls[r, :] for r < ncls, reg[r - ncls, :] for ncls <= r < ncls + nreg, cast to the dtype of the

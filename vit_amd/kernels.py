@@ -449,6 +449,23 @@ def scale_cast(g: Tensor, rows: int, N: int, out_dtype: torch.dtype, *, row_idx:
     return out
 
 
+def scale_cast_dgamma(g: Tensor, aux: Tensor, rows: int, N: int, out_dtype: torch.dtype, gamma: Tensor, *,
+                      row_idx: Optional[Tensor] = None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0):
+    """scale_cast with the layer-scale gradient from the same pass: returns (out, dgamma), dgamma[n] = alpha * sum_r
+    g[row(r), n] * aux[r, n] in the dtype of gamma."""
+    lib = L.load()
+    L.require_gpu(g, aux, gamma, row_idx)
+    g, aux = _c(g), _c(aux)
+    assert gamma.dtype == g.dtype and aux.shape[-1] == N and N <= 4096
+    out = torch.empty((rows, N), dtype=out_dtype, device=g.device)
+    dgamma = torch.empty_like(gamma)
+    ws = _workspace(lib.vitk_scale_cast_dgamma_workspace_bytes(N), g.device)
+    L.check(lib.vitk_scale_cast_dgamma(L.ptr(g), L.dt(g), N, L.ptr(row_idx), L.ptr(_c(gamma)), L.ptr(aux), L.dt(aux), L.ptr(out),
+                                       L.dt(out), L.ptr(dgamma), rows, N, alpha, drop_p, seed & 0xFFFFFFFFFFFFFFFF, L.ptr(ws),
+                                       L.stream()))
+    return out, dgamma
+
+
 def fourier_features(grid: Tensor, w: Tensor, out_dtype: torch.dtype) -> Tensor:
     """grid [N, Kc] fp32, w [Kc, J] fp32 -> [N, 2 J] = cat(sin(grid @ w), cos(grid @ w)) / sqrt(J) in out_dtype."""
     lib = L.load()

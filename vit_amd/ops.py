@@ -386,6 +386,9 @@ def _carried_bf16(dnew: Tensor, D: int) -> Optional[Tensor]:
     return shadow.view(-1, D)
 
 
+_FUSE_DGAMMA = os.environ.get("VITK_NO_FUSED_DGAMMA", "") == ""   # A/B switch: layer-scale gradient as a pass of its own
+
+
 def _residual_grad(dnew2: Tensor, tc: torch.dtype, gamma: Optional[Tensor], rows: Optional[Tensor], nrows: int, alpha: float,
                    drop_p: float, seed: int, aux: Optional[Tensor], need_dgamma: bool, shadow: Optional[Tensor] = None):
     """Gradient w.r.t. the linear's output, and w.r.t. gamma.  ``shadow``: dnew2 in bf16 if the producer supplied it."""
@@ -394,6 +397,9 @@ def _residual_grad(dnew2: Tensor, tc: torch.dtype, gamma: Optional[Tensor], rows
         return shadow, None
     if gamma is None and rows is None and alpha == 1.0 and drop_p == 0.0 and dnew2.dtype == tc:
         dy = dnew2   # nothing to scale, gather or cast (pure-bf16 parameters without layer scale or drop-path)
+    elif _FUSE_DGAMMA and gamma is not None and need_dgamma and aux is not None and N <= 4096 and N % 4 == 0:
+        # layer scale: the gradient of gamma comes out of the pass that scales and casts the branch gradient
+        return K.scale_cast_dgamma(dnew2, aux, nrows, N, tc, gamma, row_idx=rows, alpha=alpha, drop_p=drop_p, seed=seed)
     else:
         dy = K.scale_cast(dnew2, nrows, N, tc, row_idx=rows, gamma=gamma, alpha=alpha, drop_p=drop_p, seed=seed)
     dgamma = None
